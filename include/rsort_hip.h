@@ -1,0 +1,101 @@
+/* rsort_hip.h -- C-ABI of librsort_hip.so, the MI355X (gfx950) sort engine.
+ *
+ * The reference (Devil11Assassin/radix-sort) is a header-only C++20 template and has NO FFI; its
+ * only boundary is
+ *     template <typename T, typename Proj = std::identity>
+ *     void radix_sort::sort(std::vector<T>& v, Proj proj = {}, bool enableMultiThreading = false);
+ *                                                              (RadixSort/radix_sort.hpp:1628-1649)
+ * include/radix_sort.hpp in this repository keeps that signature and lowers every instantiation to
+ * the entry points below; each entry point names the reference code whose RESULT it reproduces.
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary; no exceptions; the
+ * caller owns every buffer it passes.
+ *
+ * Status codes: 0 = ok; anything else = failure, rs_last_error(ctx) describes it.  There is no CPU
+ * fallback behind any of these calls: without a usable GPU they fail.
+ */
+#ifndef RSORT_HIP_H
+#define RSORT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rs_ctx rs_ctx;
+
+enum rs_status {
+  RS_OK = 0,
+  RS_ERR_ARG = 1,      /* bad argument (width, transform, bit range, null pointer) */
+  RS_ERR_HIP = 2,      /* a HIP runtime call failed */
+  RS_ERR_KERNEL = 3,   /* a kernel reported an internal fault (look-back timeout) */
+  RS_ERR_NOMEM = 4     /* workspace allocation failed */
+};
+
+/* Key transform: how the raw bits of a key map to an order-preserving unsigned digit string.
+ *   RS_XF_NONE   unsigned integers, bool, char8: bits as they are
+ *                (radix_sort.hpp:133-137 count, :450-454 scatter)
+ *   RS_XF_SIGNED signed integers: top digit ^ 0x80  (radix_sort.hpp:138-152, :455-469)
+ *   RS_XF_IEEE   float/double: u>>63 ? ~u : u^SIGN on load, inverse on store
+ *                (radix_sort.hpp:394-416 getUnsignedVectorThread, :724-727)
+ * The transform is fused into the first read and the last write; no extra pass touches HBM. */
+enum rs_transform { RS_XF_NONE = 0, RS_XF_SIGNED = 1, RS_XF_IEEE = 2 };
+
+/* Context: one per host thread and device; owns a HIP stream (unless one is attached) and the
+ * device workspace (alternate key/value buffers, digit histograms, look-back descriptors), which
+ * grows on demand and is reused across calls.  Calls on one context are serialised on its stream.
+ * Replaces: the per-call std::vector temporaries of the reference (radix_sort.hpp:510, :646). */
+int rs_ctx_create(rs_ctx** out, int device);
+int rs_ctx_destroy(rs_ctx* ctx);
+const char* rs_last_error(const rs_ctx* ctx);
+
+/* Attach a caller-owned hipStream_t (passed as void*; NULL = the context's own stream). */
+int rs_ctx_set_stream(rs_ctx* ctx, void* hip_stream);
+/* Pre-size the workspace for n keys of key_bytes with value_bytes payload (0 = keys only), so that
+ * later sorts up to that size do not allocate. */
+int rs_ctx_reserve(rs_ctx* ctx, size_t n, int key_bytes, int value_bytes);
+/* Block until everything queued on the context's stream has finished; returns RS_ERR_KERNEL if a
+ * device-resident sort queued since the last call reported an internal fault. */
+int rs_ctx_synchronize(rs_ctx* ctx);
+
+/* Per-kernel timing with HIP events on the context's stream (for bench.py's roofline block).
+ * After a sort with profiling on, rs_ctx_get_profile fills ms[0] = histogram+scan,
+ * ms[1..passes] = the onesweep passes in order; *count = 1 + passes.  Synchronises the stream. */
+int rs_ctx_set_profiling(rs_ctx* ctx, int enabled);
+int rs_ctx_get_profile(rs_ctx* ctx, float* ms, int capacity, int* count);
+
+/* ---- device-resident entry points (pointers are device memory on the context's device) ---------
+ *
+ * rs_sort_keys_device: ascending sort of n keys of key_bytes (1, 2, 4, 8) in place.
+ *   Result == radix_sort::sort(v, {}, mt) for the matching T (value path,
+ *   radix_sort.hpp:698-729): LSD over the digits [begin_bit, end_bit) in 8-bit steps
+ *   (sortLsd :506-526; count :125-153, prefix :193-208, scatter :447-470), transform fused.
+ *   begin_bit = 0, end_bit = 8*key_bytes sorts on the whole key.
+ *   d_alt: optional caller scratch of n*key_bytes bytes (NULL = workspace). */
+int rs_sort_keys_device(rs_ctx* ctx, void* d_keys, void* d_alt, size_t n, int key_bytes,
+                        int transform, int begin_bit, int end_bit);
+
+/* rs_sort_pairs_device: STABLE ascending sort of (key, value) pairs in place; value_bytes 4 or 8.
+ *   Result == the key path of the reference (radix_sort.hpp:1160-1206 pair sortLsd,
+ *   :1062-1109 pair scatter): with values = 0..n-1 the value column is the permutation that
+ *   sortByIndices (:1111-1154) applies. */
+int rs_sort_pairs_device(rs_ctx* ctx, void* d_keys, void* d_values, void* d_alt_keys,
+                         void* d_alt_values, size_t n, int key_bytes, int value_bytes,
+                         int transform, int begin_bit, int end_bit);
+
+/* ---- host-buffer entry points (what include/radix_sort.hpp calls) --------------------------------
+ * Same contracts; buffers are host memory; H2D, sort, D2H run on the context's stream and the call
+ * returns after the data is back. */
+int rs_sort_keys(rs_ctx* ctx, void* h_keys, size_t n, int key_bytes, int transform,
+                 int begin_bit, int end_bit);
+int rs_sort_pairs(rs_ctx* ctx, void* h_keys, void* h_values, size_t n, int key_bytes,
+                  int value_bytes, int transform, int begin_bit, int end_bit);
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int rs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSORT_HIP_H */

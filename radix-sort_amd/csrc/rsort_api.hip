@@ -1,0 +1,365 @@
+// rsort_api.hip -- host side of librsort_hip.so: the C-ABI declared in include/rsort_hip.h.
+//
+// Build (see __graft_entry__.build):
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -Iinclude \
+//         radix-sort_amd/csrc/rsort_api.hip -o radix-sort_amd/lib/librsort_hip.so
+#include "rsort_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "rsort_kernels.hpp"
+
+namespace {
+
+constexpr int kMaxPasses = 8;
+constexpr int kSweepBlock = 512;
+constexpr int kSweepItems = 16;
+constexpr int kHistBlock = 512;
+constexpr size_t kTile = static_cast<size_t>(kSweepBlock) * kSweepItems;
+constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-byte descriptor
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct rs_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  DevBuf alt_keys, alt_vals, desc, ctrl;
+  // ctrl layout: [0, 16K) ghist  u64[8][256]; [16K, 32K) gbase u64[8][256];
+  //              [32K, 32K+64) tickets u32[16]; [32K+64, 32K+128) error flag (+pad)
+  bool profiling = false;
+  hipEvent_t ev[kMaxPasses + 2] = {};
+  int ev_count = 0;
+  std::string err;
+};
+
+namespace {
+
+constexpr size_t kCtrlHist = 0;
+constexpr size_t kCtrlBase = kMaxPasses * 256 * 8;
+constexpr size_t kCtrlTicket = 2 * kCtrlBase;
+constexpr size_t kCtrlError = kCtrlTicket + 64;
+constexpr size_t kCtrlBytes = kCtrlError + 64;
+
+int fail(rs_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define RS_HIP(c, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail((c), RS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+int ensure(rs_ctx* c, DevBuf& b, size_t bytes) {
+  if (b.bytes >= bytes) return RS_OK;
+  if (b.p) {
+    RS_HIP(c, hipStreamSynchronize(c->stream));
+    RS_HIP(c, hipFree(b.p));
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+  hipError_t e = hipMalloc(&b.p, bytes);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return fail(c, RS_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+  }
+  b.bytes = bytes;
+  return RS_OK;
+}
+
+size_t tiles_for(size_t n) { return (n + kTile - 1) / kTile; }
+size_t desc_bytes_for(size_t n) { return tiles_for(n) * 256 * (n <= kSmallDescLimit ? 4 : 8); }
+
+int check_args(rs_ctx* c, const void* keys, size_t n, int key_bytes, int value_bytes, int transform,
+               int begin_bit, int end_bit) {
+  if (!c) return RS_ERR_ARG;
+  if (key_bytes != 1 && key_bytes != 2 && key_bytes != 4 && key_bytes != 8)
+    return fail(c, RS_ERR_ARG, "key_bytes must be 1, 2, 4 or 8");
+  if (value_bytes != 0 && value_bytes != 4 && value_bytes != 8)
+    return fail(c, RS_ERR_ARG, "value_bytes must be 4 or 8");
+  if (transform < RS_XF_NONE || transform > RS_XF_IEEE) return fail(c, RS_ERR_ARG, "unknown transform");
+  if (transform == RS_XF_IEEE && key_bytes < 4)
+    return fail(c, RS_ERR_ARG, "RS_XF_IEEE needs 4- or 8-byte keys (radix_sort.hpp:94-98 has no other float width)");
+  if (begin_bit < 0 || end_bit > key_bytes * 8 || begin_bit >= end_bit)
+    return fail(c, RS_ERR_ARG, "need 0 <= begin_bit < end_bit <= 8*key_bytes");
+  if (n > 0 && !keys) return fail(c, RS_ERR_ARG, "null key pointer");
+  if (n >= (size_t(1) << 62)) return fail(c, RS_ERR_ARG, "n too large");
+  return RS_OK;
+}
+
+template <typename K, typename V, typename D>
+void launch_sweep(const rsk::SweepArgs& a, size_t tiles, hipStream_t s) {
+  hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kSweepBlock, kSweepItems>), dim3(static_cast<unsigned>(tiles)),
+                     dim3(kSweepBlock), 0, s, a);
+}
+
+template <typename K, typename V>
+void launch_sweep_d(const rsk::SweepArgs& a, size_t tiles, bool wide, hipStream_t s) {
+  if (wide) launch_sweep<K, V, uint64_t>(a, tiles, s);
+  else launch_sweep<K, V, uint32_t>(a, tiles, s);
+}
+
+template <typename K>
+void launch_sweep_v(const rsk::SweepArgs& a, size_t tiles, int value_bytes, bool wide, hipStream_t s) {
+  if (value_bytes == 0) launch_sweep_d<K, rsk::NoVal>(a, tiles, wide, s);
+  else if (value_bytes == 4) launch_sweep_d<K, uint32_t>(a, tiles, wide, s);
+  else launch_sweep_d<K, uint64_t>(a, tiles, wide, s);
+}
+
+void launch_sweep_k(const rsk::SweepArgs& a, size_t tiles, int key_bytes, int value_bytes, bool wide, hipStream_t s) {
+  switch (key_bytes) {
+    case 1: launch_sweep_v<uint8_t>(a, tiles, value_bytes, wide, s); break;
+    case 2: launch_sweep_v<uint16_t>(a, tiles, value_bytes, wide, s); break;
+    case 4: launch_sweep_v<uint32_t>(a, tiles, value_bytes, wide, s); break;
+    default: launch_sweep_v<uint64_t>(a, tiles, value_bytes, wide, s); break;
+  }
+}
+
+void launch_hist(const rsk::HistArgs& a, int key_bytes, unsigned grid, hipStream_t s) {
+  switch (key_bytes) {
+    case 1: hipLaunchKernelGGL((rsk::digit_histogram_kernel<uint8_t, kHistBlock>), dim3(grid), dim3(kHistBlock), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((rsk::digit_histogram_kernel<uint16_t, kHistBlock>), dim3(grid), dim3(kHistBlock), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((rsk::digit_histogram_kernel<uint32_t, kHistBlock>), dim3(grid), dim3(kHistBlock), 0, s, a); break;
+    default: hipLaunchKernelGGL((rsk::digit_histogram_kernel<uint64_t, kHistBlock>), dim3(grid), dim3(kHistBlock), 0, s, a); break;
+  }
+}
+
+// The device sort proper.  keys/vals are sorted in place; alt_* are same-size scratch.
+int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_vals, size_t n, int key_bytes,
+                int value_bytes, int transform, int begin_bit, int end_bit) {
+  if (n < 2) { c->ev_count = 0; return RS_OK; }
+  hipStream_t s = c->stream;
+  const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
+  const size_t tiles = tiles_for(n);
+  const bool wide = n > kSmallDescLimit;
+  if (tiles > 0x7FFFFFFFull) return fail(c, RS_ERR_ARG, "n too large for one launch");
+
+  int rc;
+  if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
+  if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
+  if (!alt_keys) {
+    if ((rc = ensure(c, c->alt_keys, n * key_bytes)) != RS_OK) return rc;
+    alt_keys = c->alt_keys.p;
+  }
+  if (value_bytes && !alt_vals) {
+    if ((rc = ensure(c, c->alt_vals, n * value_bytes)) != RS_OK) return rc;
+    alt_vals = c->alt_vals.p;
+  }
+
+  char* ctrl = static_cast<char*>(c->ctrl.p);
+  auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);
+  auto* gbase = reinterpret_cast<unsigned long long*>(ctrl + kCtrlBase);
+  auto* tickets = reinterpret_cast<unsigned*>(ctrl + kCtrlTicket);
+  auto* error_flag = reinterpret_cast<unsigned*>(ctrl + kCtrlError);
+
+  const uint64_t sign = 1ull << (key_bytes * 8 - 1);
+  const uint64_t all = key_bytes == 8 ? ~0ull : ((1ull << (key_bytes * 8)) - 1ull);
+  const uint64_t fmask = transform == RS_XF_IEEE ? all : 0;
+  const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
+
+  int ev = 0;
+  if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+  RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlBytes, s));
+  RS_HIP(c, hipMemsetAsync(c->desc.p, 0, desc_bytes_for(n), s));
+
+  rsk::HistArgs h{};
+  h.keys = keys; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
+  h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
+  const size_t per_block = static_cast<size_t>(kHistBlock) * 16 / key_bytes * 4;
+  unsigned hgrid = static_cast<unsigned>(std::min<size_t>((n + per_block - 1) / per_block, 256 * 8));
+  launch_hist(h, key_bytes, std::max(hgrid, 1u), s);
+  hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase);
+  if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+
+  void* kin = keys; void* kout = alt_keys;
+  void* vin = vals; void* vout = alt_vals;
+  for (int p = 0; p < passes; ++p) {
+    rsk::SweepArgs a{};
+    a.keys_in = kin; a.keys_out = kout; a.vals_in = vin; a.vals_out = vout;
+    a.desc = c->desc.p; a.ticket = tickets + p; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
+    a.n = n;
+    a.fmask_in = p == 0 ? fmask : 0; a.smask_in = p == 0 ? smask : 0;
+    a.fmask_out = p == passes - 1 ? fmask : 0; a.smask_out = p == passes - 1 ? smask : 0;
+    a.shift = begin_bit + p * rsk::kRadixBits;
+    int bits = std::min(rsk::kRadixBits, end_bit - a.shift);
+    a.mask = (1u << bits) - 1u;
+    a.incl_code = 2u + (p & 1);
+    launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, s);
+    if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+  }
+  RS_HIP(c, hipGetLastError());
+  if (passes & 1) {   // result sits in the alternate buffers
+    RS_HIP(c, hipMemcpyAsync(keys, alt_keys, n * key_bytes, hipMemcpyDeviceToDevice, s));
+    if (value_bytes) RS_HIP(c, hipMemcpyAsync(vals, alt_vals, n * value_bytes, hipMemcpyDeviceToDevice, s));
+  }
+  c->ev_count = c->profiling ? ev : 0;
+  return RS_OK;
+}
+
+int check_kernel_error(rs_ctx* c) {
+  unsigned flag = 0;
+  char* ctrl = static_cast<char*>(c->ctrl.p);
+  if (!ctrl) return RS_OK;
+  RS_HIP(c, hipMemcpyAsync(&flag, ctrl + kCtrlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+  RS_HIP(c, hipStreamSynchronize(c->stream));
+  if (flag) return fail(c, RS_ERR_KERNEL, "onesweep look-back timed out (descriptor chain broken)");
+  return RS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rs_version(void) { return 100; }
+
+int rs_ctx_create(rs_ctx** out, int device) {
+  if (!out) return RS_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return RS_ERR_HIP;
+  rs_ctx* c = new (std::nothrow) rs_ctx();
+  if (!c) return RS_ERR_NOMEM;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return RS_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) { rs_ctx_destroy(c); return RS_ERR_HIP; }
+  *out = c;
+  return RS_OK;
+}
+
+int rs_ctx_destroy(rs_ctx* c) {
+  if (!c) return RS_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->alt_keys, &c->alt_vals, &c->desc, &c->ctrl})
+    if (b->p) (void)hipFree(b->p);
+  for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return RS_OK;
+}
+
+const char* rs_last_error(const rs_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rs_ctx_set_stream(rs_ctx* c, void* hip_stream) {
+  if (!c) return RS_ERR_ARG;
+  RS_HIP(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return RS_OK;
+}
+
+int rs_ctx_reserve(rs_ctx* c, size_t n, int key_bytes, int value_bytes) {
+  int rc = check_args(c, reinterpret_cast<void*>(1), n, key_bytes, value_bytes, RS_XF_NONE, 0, key_bytes * 8);
+  if (rc != RS_OK) return rc;
+  RS_HIP(c, hipSetDevice(c->device));
+  if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
+  if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
+  if ((rc = ensure(c, c->alt_keys, n * key_bytes)) != RS_OK) return rc;
+  if (value_bytes && (rc = ensure(c, c->alt_vals, n * value_bytes)) != RS_OK) return rc;
+  return RS_OK;
+}
+
+int rs_ctx_synchronize(rs_ctx* c) {
+  if (!c) return RS_ERR_ARG;
+  return check_kernel_error(c);   // synchronises, then reports a look-back fault of any queued sort
+}
+
+int rs_ctx_set_profiling(rs_ctx* c, int enabled) {
+  if (!c) return RS_ERR_ARG;
+  c->profiling = enabled != 0;
+  c->ev_count = 0;
+  return RS_OK;
+}
+
+int rs_ctx_get_profile(rs_ctx* c, float* ms, int capacity, int* count) {
+  if (!c || !ms || !count) return RS_ERR_ARG;
+  *count = 0;
+  if (c->ev_count < 2) return RS_OK;
+  RS_HIP(c, hipEventSynchronize(c->ev[c->ev_count - 1]));
+  int k = std::min(capacity, c->ev_count - 1);
+  for (int i = 0; i < k; ++i) RS_HIP(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+  *count = k;
+  return RS_OK;
+}
+
+int rs_sort_keys_device(rs_ctx* c, void* d_keys, void* d_alt, size_t n, int key_bytes, int transform,
+                        int begin_bit, int end_bit) {
+  int rc = check_args(c, d_keys, n, key_bytes, 0, transform, begin_bit, end_bit);
+  if (rc != RS_OK) return rc;
+  RS_HIP(c, hipSetDevice(c->device));
+  return sort_device(c, d_keys, nullptr, d_alt, nullptr, n, key_bytes, 0, transform, begin_bit, end_bit);
+}
+
+int rs_sort_pairs_device(rs_ctx* c, void* d_keys, void* d_values, void* d_alt_keys, void* d_alt_values,
+                         size_t n, int key_bytes, int value_bytes, int transform, int begin_bit, int end_bit) {
+  int rc = check_args(c, d_keys, n, key_bytes, value_bytes, transform, begin_bit, end_bit);
+  if (rc != RS_OK) return rc;
+  if (value_bytes == 0) return fail(c, RS_ERR_ARG, "value_bytes must be 4 or 8");
+  if (n > 0 && !d_values) return fail(c, RS_ERR_ARG, "null value pointer");
+  RS_HIP(c, hipSetDevice(c->device));
+  return sort_device(c, d_keys, d_values, d_alt_keys, d_alt_values, n, key_bytes, value_bytes, transform,
+                     begin_bit, end_bit);
+}
+
+int rs_sort_keys(rs_ctx* c, void* h_keys, size_t n, int key_bytes, int transform, int begin_bit, int end_bit) {
+  int rc = check_args(c, h_keys, n, key_bytes, 0, transform, begin_bit, end_bit);
+  if (rc != RS_OK) return rc;
+  if (n < 2) return RS_OK;
+  RS_HIP(c, hipSetDevice(c->device));
+  // device layout: [keys | alt] in the workspace's alt_keys buffer
+  const size_t bytes = n * key_bytes;
+  const size_t padded = (bytes + 255) & ~size_t(255);
+  if ((rc = ensure(c, c->alt_keys, 2 * padded)) != RS_OK) return rc;
+  char* d = static_cast<char*>(c->alt_keys.p);
+  RS_HIP(c, hipMemcpyAsync(d, h_keys, bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = sort_device(c, d, nullptr, d + padded, nullptr, n, key_bytes, 0, transform, begin_bit, end_bit)) != RS_OK)
+    return rc;
+  RS_HIP(c, hipMemcpyAsync(h_keys, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  return check_kernel_error(c);
+}
+
+int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_bytes, int value_bytes, int transform,
+                  int begin_bit, int end_bit) {
+  int rc = check_args(c, h_keys, n, key_bytes, value_bytes, transform, begin_bit, end_bit);
+  if (rc != RS_OK) return rc;
+  if (value_bytes == 0) return fail(c, RS_ERR_ARG, "value_bytes must be 4 or 8");
+  if (n > 0 && !h_values) return fail(c, RS_ERR_ARG, "null value pointer");
+  if (n < 2) return RS_OK;
+  RS_HIP(c, hipSetDevice(c->device));
+  const size_t kb = n * key_bytes, vb = n * value_bytes;
+  const size_t kpad = (kb + 255) & ~size_t(255), vpad = (vb + 255) & ~size_t(255);
+  if ((rc = ensure(c, c->alt_keys, 2 * kpad)) != RS_OK) return rc;
+  if ((rc = ensure(c, c->alt_vals, 2 * vpad)) != RS_OK) return rc;
+  char* dk = static_cast<char*>(c->alt_keys.p);
+  char* dv = static_cast<char*>(c->alt_vals.p);
+  RS_HIP(c, hipMemcpyAsync(dk, h_keys, kb, hipMemcpyHostToDevice, c->stream));
+  RS_HIP(c, hipMemcpyAsync(dv, h_values, vb, hipMemcpyHostToDevice, c->stream));
+  if ((rc = sort_device(c, dk, dv, dk + kpad, dv + vpad, n, key_bytes, value_bytes, transform, begin_bit, end_bit)) != RS_OK)
+    return rc;
+  RS_HIP(c, hipMemcpyAsync(h_keys, dk, kb, hipMemcpyDeviceToHost, c->stream));
+  RS_HIP(c, hipMemcpyAsync(h_values, dv, vb, hipMemcpyDeviceToHost, c->stream));
+  return check_kernel_error(c);
+}
+
+}  // extern "C"
