@@ -18,8 +18,21 @@
 namespace {
 
 constexpr int kMaxPasses = 8;
-constexpr int kSweepBlock = 512;
-constexpr int kSweepItems = 16;
+// Tile geometry of the onesweep pass (overridable at build time for tuning runs).
+#ifndef RS_SWEEP_BLOCK
+#define RS_SWEEP_BLOCK 512
+#endif
+#ifndef RS_SWEEP_ITEMS
+#define RS_SWEEP_ITEMS 16
+#endif
+#ifndef RS_LOOKBACK
+#define RS_LOOKBACK 8
+#endif
+#ifndef RS_MIN_BLOCKS
+#define RS_MIN_BLOCKS 1
+#endif
+constexpr int kSweepBlock = RS_SWEEP_BLOCK;
+constexpr int kSweepItems = RS_SWEEP_ITEMS;
 constexpr int kHistBlock = 512;
 constexpr size_t kTile = static_cast<size_t>(kSweepBlock) * kSweepItems;
 constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-byte descriptor
@@ -103,7 +116,7 @@ int check_args(rs_ctx* c, const void* keys, size_t n, int key_bytes, int value_b
 
 template <typename K, typename V, typename D>
 void launch_sweep(const rsk::SweepArgs& a, size_t tiles, hipStream_t s) {
-  hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kSweepBlock, kSweepItems>), dim3(static_cast<unsigned>(tiles)),
+  hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kSweepBlock, kSweepItems, RS_LOOKBACK, RS_MIN_BLOCKS>), dim3(static_cast<unsigned>(tiles)),
                      dim3(kSweepBlock), 0, s, a);
 }
 
@@ -195,8 +208,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.fmask_in = p == 0 ? fmask : 0; a.smask_in = p == 0 ? smask : 0;
     a.fmask_out = p == passes - 1 ? fmask : 0; a.smask_out = p == passes - 1 ? smask : 0;
     a.shift = begin_bit + p * rsk::kRadixBits;
-    int bits = std::min(rsk::kRadixBits, end_bit - a.shift);
-    a.mask = (1u << bits) - 1u;
+    a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
     a.incl_code = 2u + (p & 1);
     launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, s);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
@@ -227,6 +239,12 @@ int check_kernel_error(rs_ctx* c) {
 extern "C" {
 
 int rs_version(void) { return 100; }
+
+#ifdef RS_STAMPS
+int rs_debug_read_stamps(unsigned long long* dst) {   // diagnostic builds only; not in rsort_hip.h
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(rs_stamp_buf), sizeof(unsigned long long) * 16 * 4096) == hipSuccess ? 0 : 2;
+}
+#endif
 
 int rs_ctx_create(rs_ctx** out, int device) {
   if (!out) return RS_ERR_ARG;

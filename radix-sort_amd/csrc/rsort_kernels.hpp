@@ -8,18 +8,43 @@
 //                              (replaces getPrefixVector, radix_sort.hpp:193-208)
 //   3. onesweep_kernel x P     rank-and-scatter, one read + one write of the keys per pass
 //                              (replaces getSortedVector, radix_sort.hpp:447-470 / :1062-1109);
-//                              the cross-tile prefix is a decoupled look-back chained scan
+//                              the cross-tile prefix is a single-pass chained scan (decoupled
+//                              look-back descriptors, see below)
+//
+// Look-back on MI355X.  The chip retires 30-80 tiles per microsecond while a published word needs
+// ~0.5-1 us to become visible to another CU, so a tile's nearest 20-30 predecessors are still
+// "aggregate only" when it asks.  Measured on the first version (one predecessor per dependent
+// read): 4.2 us of a 15 us tile in look-back.  The walk therefore fetches LOOKBACK predecessors
+// per round trip (independent loads, consumed in order); measured round trip = 0.45 us + 0.075 us
+// per extra row, 24 rows walked at the median.
 //
 // Memory-model notes (MI355X: 8 XCDs with private, mutually non-coherent L2s):
 //   * look-back descriptors are single 4- or 8-byte words that carry status AND value, written
 //     and polled with relaxed agent-scope atomics (sc1 stores / sc1 loads): the word is its own
 //     flag, so no fence is needed around it;
 //   * tile ids come from an atomic ticket, not blockIdx: a tile's predecessors have all started
-//     before it exists, which is the forward-progress argument for the look-back spin;
+//     before it exists, which is the forward-progress argument for the look-back spin (the spin
+//     is bounded by a wall-clock timeout anyway);
 //   * keys are written with plain stores and only read by the NEXT kernel on the same stream.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+// Diagnostic builds only, never defined in the product:
+//   -DRS_STAMPS   wave 0 / lane 0 of every 64th tile stores s_memrealtime (100 MHz) at phase
+//                 boundaries into a buffer no other code reads;
+//   -DRS_CHECKED  every output offset is range-checked; a bad one sets the error flag instead of
+//                 storing.
+#ifdef RS_STAMPS
+__device__ unsigned long long rs_stamp_buf[16 * 4096];
+#define RS_STAMP(slot)                                                                        \
+  do {                                                                                        \
+    if (tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096)                                   \
+      rs_stamp_buf[(slot) * 4096 + (tile >> 6)] = wall_clock64();                             \
+  } while (0)
+#else
+#define RS_STAMP(slot) do {} while (0)
+#endif
 
 namespace rsk {
 
@@ -48,8 +73,18 @@ template <typename K> __device__ __forceinline__ K xf_inverse(K k, K fmask, K sm
   return static_cast<K>(k ^ ((static_cast<K>(~sign_fill) & fmask) | smask));
 }
 
-template <typename K> __device__ __forceinline__ unsigned digit_at(K k, int shift, unsigned mask) {
-  return static_cast<unsigned>(k >> shift) & mask;
+// Digit extraction.  `shift`/`bits` are wave-uniform.  For 8-byte keys the digit normally lies
+// inside one 32-bit half (always, when begin_bit is a multiple of 8): one v_bfe_u32 on that half.
+template <typename K> __device__ __forceinline__ unsigned digit_at(K k, int shift, int bits) {
+  if constexpr (sizeof(K) == 8) {
+    if ((shift & 31) + bits <= 32) {
+      unsigned w = shift < 32 ? static_cast<unsigned>(k) : static_cast<unsigned>(k >> 32);
+      return __builtin_amdgcn_ubfe(w, static_cast<unsigned>(shift & 31), static_cast<unsigned>(bits));
+    }
+    return static_cast<unsigned>(k >> shift) & ((1u << bits) - 1u);
+  } else {
+    return __builtin_amdgcn_ubfe(static_cast<unsigned>(k), static_cast<unsigned>(shift), static_cast<unsigned>(bits));
+  }
 }
 
 __device__ __forceinline__ unsigned lane_id() {
@@ -69,26 +104,26 @@ struct HistArgs {
   int passes;
 };
 
+// Adds 1 to bins[d] for every active lane.  Skewed inputs (sorted shapes, few distinct values) put
+// most lanes of a wave on ONE LDS word, which the LDS serialises lane by lane: the first lane's
+// digit is peeled off -- its holders are counted by one lane in one add -- and only the other
+// lanes add individually.
+__device__ __forceinline__ void lds_count_digit(unsigned* bins, unsigned d) {
+  unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+  bool mine = d == d0;
+  unsigned long long same = __ballot(mine);
+  bool leader = mine && lane_id() == static_cast<unsigned>(__ffsll(static_cast<long long>(same)) - 1);
+  if (!mine || leader) atomicAdd(&bins[d], mine ? static_cast<unsigned>(__popcll(same)) : 1u);
+}
+
 template <typename K, int MAX_PASSES>
 __device__ __forceinline__ void hist_add_key(K k, unsigned* lh, const HistArgs& a) {
 #pragma unroll
   for (int p = 0; p < MAX_PASSES; ++p) {
     if (p < a.passes) {
       int shift = a.begin_bit + p * kRadixBits;
-      int bits = a.end_bit - shift;
-      unsigned mask = bits >= kRadixBits ? 0xFFu : ((1u << bits) - 1u);
-      unsigned d = digit_at(k, shift, mask);
-      // Skewed inputs (sorted shapes: every lane of a wave holds the same high digit) would
-      // serialise 64 ways on one LDS word: one lane adds the wave's population instead.
-      unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-      unsigned long long same = __ballot(d == d0);
-      unsigned long long act = __ballot(1);
-      if (same == act) {
-        if (lane_id() == static_cast<unsigned>(__ffsll(static_cast<long long>(act)) - 1))
-          atomicAdd(&lh[p * kRadix + d0], static_cast<unsigned>(__popcll(act)));
-      } else {
-        atomicAdd(&lh[p * kRadix + d], 1u);
-      }
+      int bits = a.end_bit - shift < kRadixBits ? a.end_bit - shift : kRadixBits;
+      lds_count_digit(lh + p * kRadix, digit_at(k, shift, bits));
     }
   }
 }
@@ -149,6 +184,7 @@ __global__ __launch_bounds__(kRadix) void digit_scan_kernel(const unsigned long 
   gbase[p * kRadix + d] = before + inc - c;
 }
 
+
 // ------------------------------------------------------------------------------------------------
 // 3. onesweep rank-and-scatter pass
 // ------------------------------------------------------------------------------------------------
@@ -183,26 +219,21 @@ struct SweepArgs {
   uint64_t fmask_in, smask_in;      // non-zero only for the first pass
   uint64_t fmask_out, smask_out;    // non-zero only for the last pass
   int shift;
-  unsigned mask;
+  int bits;
   unsigned incl_code;               // 2 + (pass & 1)
 };
 
-// Peers of this lane: the lanes of the wave whose digit equals this lane's, as a 64-bit mask
-// (8 ballots; each halves the candidate set).  `alive` removes padding lanes of a ragged tile.
-__device__ __forceinline__ unsigned long long match_digit(unsigned d, unsigned long long alive) {
-  unsigned long long m = alive;
+// Lanes of the wave whose digit DIFFERS from this lane's, as two 32-bit halves: per bit, the
+// ballot XOR the lane's own bit spread over the word (0 / ~0), ORed in (one v_bitop3 per half).
+__device__ __forceinline__ void differ_mask(unsigned d, unsigned& lo, unsigned& hi) {
+  lo = 0; hi = 0;
 #pragma unroll
   for (int b = 0; b < kRadixBits; ++b) {
-    bool bit = (d >> b) & 1u;
-    unsigned long long vote = __ballot(bit);
-    m &= bit ? vote : ~vote;
+    int sb = static_cast<int>(d << (31 - b)) >> 31;        // v_bfe_i32: 0 or -1
+    unsigned long long v = __builtin_amdgcn_sicmp(sb, 0, 40 /* ICMP_SLT */);
+    lo |= static_cast<unsigned>(v) ^ static_cast<unsigned>(sb);
+    hi |= static_cast<unsigned>(v >> 32) ^ static_cast<unsigned>(sb);
   }
-  return m;
-}
-
-__device__ __forceinline__ unsigned count_below(unsigned long long m) {   // popc(m & lanemask_lt)
-  return __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(m >> 32),
-                                   __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(m), 0u));
 }
 
 template <typename D> __device__ __forceinline__ D desc_load(const D* p) {
@@ -212,7 +243,21 @@ template <typename D> __device__ __forceinline__ void desc_store(D* p, D v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename V> struct ValHolder { V v; };
+// Bounded wait helper: call once per unsuccessful poll; true = give up (timeout, or another
+// workgroup already reported a fault).  ~2 s of wall clock (s_memrealtime ticks at 100 MHz).
+struct SpinGuard {
+  unsigned spins = 0;
+  long long t0 = 0;
+  __device__ __forceinline__ bool expired(unsigned* error_flag) {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 255u) != 0) return false;
+    long long now = static_cast<long long>(wall_clock64());
+    if (t0 == 0) t0 = now;
+    return now - t0 > 200000000ll ||
+           __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  }
+};
+
 struct NoVal {};
 
 template <typename K, typename V, typename D, int BLOCK, int ITEMS>
@@ -222,31 +267,39 @@ struct SweepSmem {
   static constexpr bool HAS_VAL = !__is_same(V, NoVal);
   static constexpr size_t kElem = HAS_VAL ? (sizeof(V) > sizeof(K) ? sizeof(V) : sizeof(K)) : sizeof(K);
   alignas(16) unsigned char stage[TILE * kElem];
-  unsigned whist[WAVES][kRadix];
-  unsigned tile_start[kRadix];
-  D gofs[kRadix];
+  unsigned whist[WAVES][kRadix];    // per wave: running digit counts, later tile_start + wave prefix
+  unsigned tile_start[kRadix];      // exclusive scan of the tile's digit counts
+  D gofs[kRadix];                   // global offset of the digit's run minus tile_start
   unsigned wave_total[kRadix / kWave];
   unsigned tile_id;
 };
 
-template <typename K, typename V, typename D, int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void onesweep_kernel(SweepArgs a) {
+template <typename K, typename V, typename D, int BLOCK, int ITEMS, int LOOKBACK = 8, int MIN_BLOCKS = 1>
+__global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesweep_kernel(SweepArgs a) {
   using Smem = SweepSmem<K, V, D, BLOCK, ITEMS>;
   constexpr int WAVES = Smem::WAVES;
   constexpr int TILE = Smem::TILE;
   constexpr bool HAS_VAL = Smem::HAS_VAL;
+  static_assert(BLOCK >= kRadix, "one thread per digit");
   __shared__ Smem s;
 
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & (kWave - 1);
   const unsigned wave = tid / kWave;
 
+#ifdef RS_STAMPS
+  unsigned long long stamp_begin = wall_clock64();
+#endif
   if (tid == 0) s.tile_id = atomicAdd(a.ticket, 1u);
 #pragma unroll
   for (int i = 0; i < kRadix / kWave; ++i) s.whist[wave][i * kWave + lane] = 0;
   __syncthreads();
 
   const uint64_t tile = s.tile_id;
+#ifdef RS_STAMPS
+  if (tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096) rs_stamp_buf[tile >> 6] = stamp_begin;
+#endif
+  RS_STAMP(1);
   const uint64_t tile_base = tile * TILE;
   const unsigned tile_count = (a.n - tile_base) < static_cast<uint64_t>(TILE)
                                   ? static_cast<unsigned>(a.n - tile_base) : static_cast<unsigned>(TILE);
@@ -254,61 +307,77 @@ __global__ __launch_bounds__(BLOCK) void onesweep_kernel(SweepArgs a) {
 
   const K* kin = static_cast<const K*>(a.keys_in) + tile_base;
   const K fmi = static_cast<K>(a.fmask_in), smi = static_cast<K>(a.smask_in);
+  const bool xf_in = (a.fmask_in | a.smask_in) != 0;
 
   // ---- load: wave-striped, so (item, lane) order == key order inside the wave's segment ----------
   K key[ITEMS];
   const unsigned seg = wave * (kWave * ITEMS) + lane;
   if (full) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) key[i] = xf_forward(kin[seg + i * kWave], fmi, smi);
+    for (int i = 0; i < ITEMS; ++i) key[i] = kin[seg + i * kWave];
   } else {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       unsigned idx = seg + i * kWave;
-      key[i] = idx < tile_count ? xf_forward(kin[idx], fmi, smi) : static_cast<K>(~static_cast<K>(0));
+      key[i] = idx < tile_count ? kin[idx] : static_cast<K>(0);
     }
   }
+  if (xf_in) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) key[i] = xf_forward(key[i], fmi, smi);
+  }
+#ifdef RS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RS_STAMP(2);
 
   // ---- rank inside the wave -----------------------------------------------------------------------
   // After round i, whist[wave][d] = number of digit-d keys in rounds 0..i; rank = (count before
   // the round) + (peers in lower lanes).  Lane order inside a round and round order inside the
   // wave are both key order, so equal digits keep their input order (stability).
-  unsigned rank[ITEMS];
+  // The LDS executes one wave's operations in order, so round i+1's read of whist sees round i's
+  // add without any wait in the instruction stream: 2 x ITEMS LDS operations stay in flight and no
+  // register dependency links the rounds.
+  unsigned short rank[ITEMS];
+  unsigned char dig[ITEMS];
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
-    unsigned d = digit_at(key[i], a.shift, a.mask);
-    bool ok = full || (seg + i * kWave) < tile_count;
-    unsigned long long alive = full ? ~0ull : __ballot(ok);
-    unsigned long long peers = match_digit(d, alive);
-    unsigned below = count_below(peers);
+    unsigned d = digit_at(key[i], a.shift, a.bits);
+    dig[i] = static_cast<unsigned char>(d);
+    unsigned dlo, dhi;
+    differ_mask(d, dlo, dhi);
+    unsigned plo = ~dlo, phi = ~dhi;                   // peers: lanes holding the same digit
+    bool ok = true;
+    if (!full) {
+      ok = (seg + i * kWave) < tile_count;
+      unsigned long long alive = __ballot(ok);
+      plo &= static_cast<unsigned>(alive);
+      phi &= static_cast<unsigned>(alive >> 32);
+    }
+    unsigned below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
     unsigned before = s.whist[wave][d];
-    __builtin_amdgcn_wave_barrier();
-    if (ok && below == 0) s.whist[wave][d] = before + static_cast<unsigned>(__popcll(peers));
-    __builtin_amdgcn_wave_barrier();
-    rank[i] = before + below;
+    if (ok && below == 0) atomicAdd(&s.whist[wave][d], static_cast<unsigned>(__popc(plo) + __popc(phi)));
+    rank[i] = static_cast<unsigned short>(before + below);
   }
   __syncthreads();
+  RS_STAMP(3);
 
-  // ---- per-digit: counts over waves, publish the aggregate, scan over digits ---------------------
+  // ---- per digit: tile count, publish the aggregate, scan over digits -----------------------------
   D* desc = static_cast<D*>(a.desc);
   unsigned my_count = 0;
   unsigned inc = 0;
   if (tid < kRadix) {
     unsigned sum = 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-      unsigned c = s.whist[w][tid];
-      s.whist[w][tid] = sum;          // becomes: digit-d keys in lower waves
-      sum += c;
-    }
+    for (int w = 0; w < WAVES; ++w) sum += s.whist[w][tid];
     my_count = sum;
     D word = (static_cast<D>(tile == 0 ? a.incl_code : kCodeAgg) << Desc<D>::kShift) | static_cast<D>(sum);
     desc_store(&desc[tile * kRadix + tid], word);
     unsigned v = sum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
-      unsigned t = __shfl_up(v, off, kWave);
-      if (lane >= static_cast<unsigned>(off)) v += t;
+      unsigned u = __shfl_up(v, off, kWave);
+      if (lane >= static_cast<unsigned>(off)) v += u;
     }
     inc = v;
     if (lane == kWave - 1) s.wave_total[wave] = v;
@@ -317,45 +386,56 @@ __global__ __launch_bounds__(BLOCK) void onesweep_kernel(SweepArgs a) {
   if (tid < kRadix) {
     unsigned before = 0;
     for (unsigned w = 0; w < wave; ++w) before += s.wave_total[w];
-    s.tile_start[tid] = before + inc - my_count;
+    unsigned start = before + inc - my_count;
+    s.tile_start[tid] = start;
+    unsigned sum = start;               // fold tile_start into the wave prefix: one LDS read per key later
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      unsigned c = s.whist[w][tid];
+      s.whist[w][tid] = sum;
+      sum += c;
+    }
   }
   __syncthreads();
+  RS_STAMP(4);
 
   // ---- stage keys in LDS in digit order -------------------------------------------------------------
   K* stage_k = reinterpret_cast<K*>(s.stage);
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
-    unsigned d = digit_at(key[i], a.shift, a.mask);
-    unsigned pos = s.tile_start[d] + s.whist[wave][d] + rank[i];
-    rank[i] = pos;
+    unsigned pos = s.whist[wave][dig[i]] + rank[i];
+    rank[i] = static_cast<unsigned short>(pos);
     if (full || (seg + i * kWave) < tile_count) stage_k[pos] = key[i];
   }
+  RS_STAMP(5);
 
-  // ---- decoupled look-back: one thread per digit -----------------------------------------------------
+  // ---- decoupled look-back: one thread per digit, LOOKBACK predecessors per round trip --------------
   if (tid < kRadix) {
     unsigned long long excl = 0;
     if (tile > 0) {
-      uint64_t t = tile - 1;
-      unsigned spins = 0;
-      long long t0 = 0;
+      long long t = static_cast<long long>(tile) - 1;     // next predecessor to consume
+      SpinGuard guard;
       bool failed = false;
       while (true) {
-        D w = desc_load(&desc[t * kRadix + tid]);
-        unsigned code = static_cast<unsigned>(w >> Desc<D>::kShift);
-        if (code == a.incl_code) { excl += static_cast<unsigned long long>(w & Desc<D>::kValueMask); break; }
-        if (code == kCodeAgg) { excl += static_cast<unsigned long long>(w & Desc<D>::kValueMask); --t; spins = 0; continue; }
-        // predecessor has not published yet: back off; give up after ~2 s of wall clock so a
-        // broken invariant ends the kernel instead of hanging the device.
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 1023u) == 0) {
-          long long now = static_cast<long long>(wall_clock64());
-          if (t0 == 0) t0 = now;
-          if (now - t0 > 200000000ll ||
-              __hip_atomic_load(a.error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            failed = true;
-            break;
+        D w[LOOKBACK];
+#pragma unroll
+        for (int j = 0; j < LOOKBACK; ++j) {
+          long long tt = t - j;
+          w[j] = desc_load(&desc[static_cast<uint64_t>(tt < 0 ? 0 : tt) * kRadix + tid]);
+        }
+        bool done = false;
+        int consumed = 0;
+#pragma unroll
+        for (int j = 0; j < LOOKBACK; ++j) {
+          if (!done && consumed == j) {
+            unsigned code = static_cast<unsigned>(w[j] >> Desc<D>::kShift);
+            if (code == a.incl_code) { excl += static_cast<unsigned long long>(w[j] & Desc<D>::kValueMask); done = true; }
+            else if (code == kCodeAgg) { excl += static_cast<unsigned long long>(w[j] & Desc<D>::kValueMask); ++consumed; }
           }
         }
+        if (done) break;
+        t -= consumed;
+        if (consumed == 0 && guard.expired(a.error_flag)) { failed = true; break; }
       }
       if (failed) __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       D word = (static_cast<D>(a.incl_code) << Desc<D>::kShift) |
@@ -365,21 +445,30 @@ __global__ __launch_bounds__(BLOCK) void onesweep_kernel(SweepArgs a) {
     s.gofs[tid] = static_cast<D>(a.gbase[tid] + excl - s.tile_start[tid]);
   }
   __syncthreads();
+  RS_STAMP(6);
 
   // ---- write out: consecutive threads write consecutive addresses inside each digit run -------------
   K* kout = static_cast<K*>(a.keys_out);
   const K fmo = static_cast<K>(a.fmask_out), smo = static_cast<K>(a.smask_out);
+  const bool xf_out = (a.fmask_out | a.smask_out) != 0;
   D dst[HAS_VAL ? ITEMS : 1];
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     unsigned j = i * BLOCK + tid;
     if (full || j < tile_count) {
       K k = stage_k[j];
-      D o = s.gofs[digit_at(k, a.shift, a.mask)] + j;
-      kout[o] = xf_inverse(k, fmo, smo);
+      D o = s.gofs[digit_at(k, a.shift, a.bits)] + j;
+#ifdef RS_CHECKED
+      if (static_cast<uint64_t>(o) >= a.n) { __hip_atomic_store(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
+#endif
+      kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
       if constexpr (HAS_VAL) dst[i] = o;
     }
   }
+#ifdef RS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  RS_STAMP(7);
 
   if constexpr (HAS_VAL) {
     const V* vin = static_cast<const V*>(a.vals_in) + tile_base;

@@ -1,0 +1,120 @@
+// rs_tune.hip -- developer harness: times one build of librsort_hip.so (path given) on synthetic
+// keys, device-resident, and verifies order on the device.  Not part of the product or the tests.
+//   hipcc -O2 --offload-arch=gfx950 tools/rs_tune.hip -o tools/rs_tune -ldl
+//   tools/rs_tune <lib.so> <key_bytes> <log2n|n> <shape: random|sorted|reverse|nearly|dups> [iters] [value_bytes]
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../include/rsort_hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(2); } } while (0)
+
+__device__ inline uint64_t mix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+}
+template <typename K> __global__ void gen(K* k, uint64_t n, int shape) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t umax = sizeof(K) == 8 ? ~0ull : 0xFFFFFFFFull;
+  const uint64_t step = umax / (n - 1);
+  for (; i < n; i += stride) {
+    uint64_t v;
+    if (shape == 0) v = mix(i);
+    else if (shape == 4) v = mix(mix(i) & 255);
+    else {
+      uint64_t j = i;
+      if (shape == 2) j = n - 1 - i;
+      if (shape == 3 && (mix(i * 7 + 1) % 20) == 0) { uint64_t o = mix(i * 3 + 5) % n; j = o; }  // ~5% displaced
+      v = j * step;
+    }
+    k[i] = (K)v;
+  }
+}
+template <typename K> __global__ void check(const K* k, uint64_t n, unsigned* bad, unsigned long long* sum) {
+  uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long s = 0; unsigned b = 0;
+  for (; i < n; i += stride) { s += (unsigned long long)k[i]; if (i + 1 < n && k[i] > k[i + 1]) b++; }
+  if (b) atomicAdd(bad, b);
+  atomicAdd(sum, s);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 5) { printf("usage\n"); return 1; }
+  void* h = dlopen(argv[1], RTLD_NOW);
+  if (!h) { printf("dlopen: %s\n", dlerror()); return 1; }
+  auto f_create = (int (*)(rs_ctx**, int))dlsym(h, "rs_ctx_create");
+  auto f_sort = (int (*)(rs_ctx*, void*, void*, size_t, int, int, int, int))dlsym(h, "rs_sort_keys_device");
+  auto f_pairs = (int (*)(rs_ctx*, void*, void*, void*, void*, size_t, int, int, int, int, int))dlsym(h, "rs_sort_pairs_device");
+  auto f_sync = (int (*)(rs_ctx*))dlsym(h, "rs_ctx_synchronize");
+  auto f_prof = (int (*)(rs_ctx*, int))dlsym(h, "rs_ctx_set_profiling");
+  auto f_get = (int (*)(rs_ctx*, float*, int, int*))dlsym(h, "rs_ctx_get_profile");
+  auto f_err = (const char* (*)(const rs_ctx*))dlsym(h, "rs_last_error");
+  int kb = atoi(argv[2]);
+  uint64_t n = strtoull(argv[3], 0, 10); if (n <= 40) n = 1ull << n;
+  int shape = !strcmp(argv[4], "random") ? 0 : !strcmp(argv[4], "sorted") ? 1 : !strcmp(argv[4], "reverse") ? 2 : !strcmp(argv[4], "nearly") ? 3 : 4;
+  int iters = argc > 5 ? atoi(argv[5]) : 5;
+  int vb = argc > 6 ? atoi(argv[6]) : 0;
+  rs_ctx* c = nullptr;
+  if (f_create(&c, 0)) { printf("ctx create failed\n"); return 1; }
+  void *src, *work, *alt, *vals = nullptr, *valt = nullptr; unsigned* bad; unsigned long long* sums;
+  CK(hipMalloc(&src, n * kb)); CK(hipMalloc(&work, n * kb)); CK(hipMalloc(&alt, n * kb));
+  if (vb) { CK(hipMalloc(&vals, n * vb)); CK(hipMalloc(&valt, n * vb)); CK(hipMemset(vals, 0, n * vb)); }
+  CK(hipMalloc(&bad, 4)); CK(hipMalloc(&sums, 16)); CK(hipMemset(bad, 0, 4)); CK(hipMemset(sums, 0, 16));
+  if (kb == 4) gen<uint32_t><<<2048, 256>>>((uint32_t*)src, n, shape); else gen<uint64_t><<<2048, 256>>>((uint64_t*)src, n, shape);
+  if (kb == 4) check<uint32_t><<<2048, 256>>>((uint32_t*)src, n, bad, sums); else check<uint64_t><<<2048, 256>>>((uint64_t*)src, n, bad, sums);
+  CK(hipDeviceSynchronize());
+  f_prof(c, 1);
+  std::vector<float> tot, hist, pass;
+  for (int it = 0; it < iters + 2; ++it) {
+    CK(hipMemcpy(work, src, n * kb, hipMemcpyDeviceToDevice));
+    CK(hipDeviceSynchronize());
+    int rc = vb ? f_pairs(c, work, vals, alt, valt, n, kb, vb, 0, 0, kb * 8) : f_sort(c, work, alt, n, kb, 0, 0, kb * 8);
+    if (rc) { printf("sort failed: %s\n", f_err(c)); return 1; }
+    if (f_sync(c)) { printf("sync failed: %s\n", f_err(c)); return 1; }
+    float ms[16]; int cnt = 0; f_get(c, ms, 16, &cnt);
+    if (it >= 2) { float t = 0; for (int i = 0; i < cnt; ++i) t += ms[i]; tot.push_back(t); hist.push_back(ms[0]); for (int i = 1; i < cnt; ++i) pass.push_back(ms[i]); }
+  }
+  CK(hipMemset(bad, 0, 4));
+  if (kb == 4) check<uint32_t><<<2048, 256>>>((uint32_t*)work, n, bad, sums + 1); else check<uint64_t><<<2048, 256>>>((uint64_t*)work, n, bad, sums + 1);
+  unsigned hb; unsigned long long hs[2];
+  CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, sums, 16, hipMemcpyDeviceToHost));
+  std::sort(tot.begin(), tot.end()); std::sort(hist.begin(), hist.end()); std::sort(pass.begin(), pass.end());
+  double t = tot[tot.size() / 2];
+  double canon = (double)n * (kb + 2.0 * kb * (kb + vb));
+  printf("%-40s kb=%d vb=%d n=%llu %-7s total %.3f ms  hist %.3f  pass(med) %.3f (min %.3f max %.3f)  %.1f Gkeys/s  roofline %.1f%%  %s\n",
+         strrchr(argv[1], '/') ? strrchr(argv[1], '/') + 1 : argv[1], kb, vb, (unsigned long long)n, argv[4], t, hist[hist.size() / 2],
+         pass[pass.size() / 2], pass.front(), pass.back(), n / t / 1e6, canon / (t * 1e-3) / 8e12 * 100,
+         (hb == 0 && hs[0] == hs[1]) ? "OK" : "WRONG");
+  auto f_st = (int (*)(unsigned long long*))dlsym(h, "rs_debug_read_stamps");
+  if (f_st) {
+    std::vector<unsigned long long> st(16 * 4096);
+    f_st(st.data());
+    size_t tiles = (n + 8191) / 8192, cnt = std::min<size_t>(tiles / 64, 4096);
+    const char* names[] = {"begin->ticket", "ticket->counted", "counted->ranked", "ranked->scanned", "scanned->staged", "staged->lookedback", "lookedback->written"};
+    for (int k = 0; k < 7; ++k) {
+      std::vector<double> d;
+      for (size_t i = 8; i < cnt; ++i) d.push_back((double)(long long)(st[(k + 1) * 4096 + i] - st[k * 4096 + i]) * 0.01);
+      std::sort(d.begin(), d.end());
+      if (!d.empty()) printf("   %-22s median %.2f us  p10 %.2f  p90 %.2f\n", names[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+    }
+  }
+  if (f_st) {
+    std::vector<unsigned long long> st(16 * 4096);
+    f_st(st.data());
+    size_t tiles = (n + 8191) / 8192, cnt = std::min<size_t>(tiles / 64, 4096);
+    const char* nm[] = {"lookback trips", "empty trips", "tiles walked"};
+    for (int k = 0; k < 3; ++k) {
+      std::vector<double> d;
+      for (size_t i = 8; i < cnt; ++i) d.push_back((double)st[(8 + k) * 4096 + i]);
+      std::sort(d.begin(), d.end());
+      if (!d.empty()) printf("   %-22s median %.0f  p10 %.0f  p90 %.0f max %.0f\n", nm[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10], d.back());
+    }
+  }
+  return (hb == 0 && hs[0] == hs[1]) ? 0 : 3;
+}
