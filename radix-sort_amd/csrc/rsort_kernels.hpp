@@ -106,21 +106,31 @@ struct HistArgs {
 
 // Adds 1 to bins[d] for every active lane.  Skewed inputs (sorted shapes, few distinct values) put
 // most lanes of a wave on ONE LDS word, which the LDS serialises lane by lane: the first lane's
-// digit is peeled off -- its holders are counted by one lane in one add -- and only the other
-// lanes add individually.
+// digit is peeled off when at least 8 lanes hold it -- its holders are counted by one lane in one
+// add -- and only the other lanes add individually.
 __device__ __forceinline__ void lds_count_digit(unsigned* bins, unsigned d) {
   unsigned d0 = __builtin_amdgcn_readfirstlane(d);
   bool mine = d == d0;
   unsigned long long same = __ballot(mine);
-  bool leader = mine && lane_id() == static_cast<unsigned>(__ffsll(static_cast<long long>(same)) - 1);
-  if (!mine || leader) atomicAdd(&bins[d], mine ? static_cast<unsigned>(__popcll(same)) : 1u);
+  if (__popcll(same) >= 8) {           // wave-uniform: worth peeling
+    bool leader = mine && __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
+                                                    __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u)) == 0;
+    if (!mine || leader) atomicAdd(&bins[d], mine ? static_cast<unsigned>(__popcll(same)) : 1u);
+  } else {
+    atomicAdd(&bins[d], 1u);
+  }
 }
 
-template <typename K, int MAX_PASSES>
+// WHOLE = the sort covers the whole key in byte-aligned digits (begin_bit 0, end_bit 8*sizeof(K)):
+// every shift is a compile-time constant (one v_bfe_u32 with immediates per digit).
+template <typename K, int MAX_PASSES, bool WHOLE>
 __device__ __forceinline__ void hist_add_key(K k, unsigned* lh, const HistArgs& a) {
 #pragma unroll
   for (int p = 0; p < MAX_PASSES; ++p) {
-    if (p < a.passes) {
+    if constexpr (WHOLE) {
+      unsigned w = sizeof(K) == 8 && p >= 4 ? static_cast<unsigned>(static_cast<uint64_t>(k) >> 32) : static_cast<unsigned>(k);
+      lds_count_digit(lh + p * kRadix, (w >> ((p & 3) * 8)) & 0xFFu);
+    } else if (p < a.passes) {
       int shift = a.begin_bit + p * kRadixBits;
       int bits = a.end_bit - shift < kRadixBits ? a.end_bit - shift : kRadixBits;
       lds_count_digit(lh + p * kRadix, digit_at(k, shift, bits));
@@ -128,7 +138,7 @@ __device__ __forceinline__ void hist_add_key(K k, unsigned* lh, const HistArgs& 
   }
 }
 
-template <typename K, int BLOCK>
+template <typename K, int BLOCK, bool WHOLE>
 __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
   constexpr int MAX_PASSES = sizeof(K);
   constexpr int VEC = 16 / sizeof(K);            // 16 bytes per lane per load
@@ -145,11 +155,11 @@ __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
        i += static_cast<uint64_t>(gridDim.x) * BLOCK) {
     Pack pk = vkeys[i];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) hist_add_key<K, MAX_PASSES>(xf_forward(pk.v[j], fm, sm), lh, a);
+    for (int j = 0; j < VEC; ++j) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(pk.v[j], fm, sm), lh, a);
   }
   if (blockIdx.x == 0) {                          // tail (n not a multiple of VEC)
     uint64_t i = nvec * VEC + threadIdx.x;
-    if (i < a.n) hist_add_key<K, MAX_PASSES>(xf_forward(keys[i], fm, sm), lh, a);
+    if (i < a.n) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(keys[i], fm, sm), lh, a);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < a.passes * kRadix; i += BLOCK) {
