@@ -1,0 +1,256 @@
+// radix_sort.hpp -- drop-in front-end for the reference's public API, executed on MI355X.
+//
+//     template <typename T, typename Proj = std::identity>
+//     void radix_sort::sort(std::vector<T>& v, Proj proj = {}, bool enableMultiThreading = false);
+//
+// Same name, signature, accepted types and compile-time diagnostics as the reference
+// (RadixSort/radix_sort.hpp:1628-1649; concepts :65-92); same results: ascending order for
+// integers, IEEE-754 totalOrder for float/double, std::string::operator< order for strings, and
+// the unique STABLE permutation for projected keys (README.md:62-67).  Every instantiation lowers
+// to the C-ABI of librsort_hip.so (include/rsort_hip.h); there is no CPU sort in this header --
+// without the library or a GPU the call throws std::runtime_error.
+//
+// How each reference strategy maps (radix_sort.hpp line numbers):
+//   value path, numeric T   (:698-729)    -> rs_sort_keys, transform fused on the device
+//   value path, std::string (:528-586)    -> pack to blob+offsets, rs_sort_strings, move by permutation
+//   key path, numeric key   (:1543-1592)  -> key column + index payload, rs_sort_pairs (stable),
+//                                            then the moves of sortByIndices (:1111-1133)
+//   key path, string key    (:1574-1578)  -> pack projected strings, rs_sort_strings (stable), moves
+// The third argument is accepted for source compatibility; the device path is always parallel.
+// The reference's pre-checks (already sorted -> return, :269-305 / :746-769) and insertion-sort
+// thresholds (:42-43) change its running time, never its result, and are not reproduced.
+//
+// Link with:  -L<repo>/radix-sort_amd/lib -lrsort_hip
+#pragma once
+#include <concepts>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "rsort_hip.h"
+
+namespace radix_sort
+{
+	namespace internal
+	{
+		namespace shared
+		{
+			template <typename T>
+			concept is_string = std::same_as<T, std::string>;
+
+			template <typename T>
+			concept supported = std::integral<T> || std::floating_point<T> || is_string<T>;
+
+			template <typename T, typename Proj>
+			using invoke_result = std::invoke_result_t<Proj&, const T&>;
+
+			template <typename T, typename Proj>
+			using sort_key = std::remove_cvref_t<std::invoke_result_t<Proj&, const T&>>;
+
+			template <typename T, typename Proj>
+			concept sortable = requires(Proj proj, const T& t) {
+				{ std::invoke(proj, t) } -> std::same_as<invoke_result<T, Proj>>;
+			} && supported<sort_key<T, Proj>>;
+		}
+
+		namespace device
+		{
+			struct CtxDeleter { void operator()(rs_ctx* c) const { rs_ctx_destroy(c); } };
+
+			// One context per host thread (rsort_hip.h: calls on a context are serialised on its stream).
+			inline rs_ctx* context()
+			{
+				thread_local std::unique_ptr<rs_ctx, CtxDeleter> ctx;
+				if (!ctx)
+				{
+					const char* dev = std::getenv("RSORT_DEVICE");
+					rs_ctx* raw = nullptr;
+					if (rs_ctx_create(&raw, dev ? std::atoi(dev) : 0) != RS_OK)
+						throw std::runtime_error("radix_sort::sort: no usable GPU (rs_ctx_create failed)");
+					ctx.reset(raw);
+				}
+				return ctx.get();
+			}
+
+			inline void check(rs_ctx* ctx, int status)
+			{
+				if (status != RS_OK)
+					throw std::runtime_error(std::string("radix_sort::sort: ") + rs_last_error(ctx));
+			}
+
+			template <typename Key>
+			constexpr int transformOf()
+			{
+				if constexpr (std::floating_point<Key>) return RS_XF_IEEE;
+				else if constexpr (std::signed_integral<Key>) return RS_XF_SIGNED;
+				else return RS_XF_NONE;
+			}
+
+			template <typename Key>
+			constexpr void checkKeyType()
+			{
+				static_assert(sizeof(Key) == 1 || sizeof(Key) == 2 || sizeof(Key) == 4 || sizeof(Key) == 8,
+					"ERROR: Unable to sort vector! CAUSE: Unsupported key width!");   // t2u has no other case (:94-98)
+				if constexpr (std::floating_point<Key>)
+					static_assert(std::numeric_limits<Key>::is_iec559,
+						"ERROR: generators.hpp requires IEEE-754/IEC-559 compliance.\n");   // :701-707
+			}
+
+			// tmp[i] = move(v[perm[i]]), then swap: the single-threaded body of sortByIndices (:1126-1132)
+			template <typename T, typename I>
+			inline void applyPermutation(std::vector<T>& v, const std::vector<I>& perm)
+			{
+				std::vector<T> tmp;
+				tmp.reserve(v.size());
+				for (const auto& i : perm)
+					tmp.emplace_back(std::move(v[static_cast<std::size_t>(i)]));
+				std::swap(tmp, v);
+			}
+
+			struct PackedStrings
+			{
+				std::vector<std::uint8_t> blob;
+				std::vector<std::uint64_t> offsets;
+			};
+
+			template <typename T, typename Proj>
+			inline PackedStrings packStrings(const std::vector<T>& v, Proj& proj)
+			{
+				PackedStrings p;
+				p.offsets.resize(v.size() + 1);
+				std::uint64_t total = 0;
+				for (std::size_t i = 0; i < v.size(); i++)
+				{
+					p.offsets[i] = total;
+					total += std::invoke(proj, v[i]).size();
+				}
+				p.offsets[v.size()] = total;
+				p.blob.resize(total);
+				for (std::size_t i = 0; i < v.size(); i++)
+				{
+					const std::string& s = std::invoke(proj, v[i]);
+					std::copy(s.begin(), s.end(), p.blob.begin() + static_cast<std::ptrdiff_t>(p.offsets[i]));
+				}
+				return p;
+			}
+
+			template <typename T, typename Proj>
+			inline void sortByStringKey(std::vector<T>& v, Proj& proj, bool stable)
+			{
+				PackedStrings p = packStrings(v, proj);
+				std::vector<std::uint64_t> perm(v.size());
+				rs_ctx* ctx = context();
+				check(ctx, rs_sort_strings(ctx, p.blob.data(), p.offsets.data(), v.size(), perm.data(), stable ? 1 : 0));
+				applyPermutation(v, perm);
+			}
+		}
+
+		namespace value
+		{
+			template <shared::supported T>
+			inline void sortDispatcher(std::vector<T>& v, bool /*enableMultiThreading*/)
+			{
+				if (v.size() < 2)
+					return;
+
+				if constexpr (shared::is_string<T>)
+				{
+					std::identity id;
+					device::sortByStringKey(v, id, false);
+				}
+				else
+				{
+					static_assert(!std::same_as<T, bool>,
+						"ERROR: Unable to sort vector! CAUSE: std::vector<bool> has no element storage!");
+					device::checkKeyType<T>();
+					rs_ctx* ctx = device::context();
+					device::check(ctx, rs_sort_keys(ctx, v.data(), v.size(), static_cast<int>(sizeof(T)),
+						device::transformOf<T>(), 0, static_cast<int>(sizeof(T)) * 8));
+				}
+			}
+		}
+
+		namespace key
+		{
+			template <typename T, typename Proj>
+			requires shared::sortable<T, Proj>
+			inline void sortDispatcher(std::vector<T>& v, Proj proj, bool /*enableMultiThreading*/)
+			{
+				using Key = shared::sort_key<T, Proj>;
+				const std::size_t SIZE = v.size();
+				if (SIZE < 2)
+					return;
+
+				if constexpr (shared::is_string<Key>)
+				{
+					device::sortByStringKey(v, proj, true);
+				}
+				else
+				{
+					device::checkKeyType<Key>();
+
+					std::vector<Key> k;                       // the key column (:1581-1585)
+					k.reserve(SIZE);
+					for (const auto& obj : v)
+						k.emplace_back(std::invoke(proj, obj));
+
+					rs_ctx* ctx = device::context();
+					constexpr int XF = device::transformOf<Key>();
+					constexpr int BITS = static_cast<int>(sizeof(Key)) * 8;
+
+					if (SIZE <= std::numeric_limits<std::uint32_t>::max())
+					{
+						std::vector<std::uint32_t> indices(SIZE);   // iota (:1571-1572), 4-byte payload
+						for (std::size_t i = 0; i < SIZE; i++)
+							indices[i] = static_cast<std::uint32_t>(i);
+						device::check(ctx, rs_sort_pairs(ctx, k.data(), indices.data(), SIZE, static_cast<int>(sizeof(Key)), 4, XF, 0, BITS));
+						device::applyPermutation(v, indices);
+					}
+					else
+					{
+						std::vector<std::uint64_t> indices(SIZE);
+						for (std::size_t i = 0; i < SIZE; i++)
+							indices[i] = i;
+						device::check(ctx, rs_sort_pairs(ctx, k.data(), indices.data(), SIZE, static_cast<int>(sizeof(Key)), 8, XF, 0, BITS));
+						device::applyPermutation(v, indices);
+					}
+				}
+			}
+		}
+	}
+
+	// =============
+	// -----API-----
+	// =============
+
+	template <typename T, typename Proj = std::identity>
+	inline void sort(std::vector<T>& v, Proj proj = {}, bool enableMultiThreading = false)
+	{
+		if constexpr (std::same_as<std::remove_cvref_t<Proj>, std::identity>)
+		{
+			static_assert(
+				internal::shared::supported<T>,
+				"ERROR: Unable to sort vector! CAUSE: Unsupported type!"
+			);
+
+			internal::value::sortDispatcher(v, enableMultiThreading);
+		}
+		else
+		{
+			static_assert(
+				internal::shared::sortable<T, Proj>,
+				"ERROR: Unable to sort vector! CAUSE: Key extractor is invalid or returns an unsupported type!"
+			);
+
+			internal::key::sortDispatcher(v, proj, enableMultiThreading);
+		}
+	}
+};

@@ -92,6 +92,17 @@ int rs_sort_keys(rs_ctx* ctx, void* h_keys, size_t n, int key_bytes, int transfo
 int rs_sort_pairs(rs_ctx* ctx, void* h_keys, void* h_values, size_t n, int key_bytes,
                   int value_bytes, int transform, int begin_bit, int end_bit);
 
+/* rs_sort_strings: order of n byte strings; string i is h_blob[h_offsets[i] .. h_offsets[i+1]).
+ *   On return h_perm[i] = index of the string that belongs at position i; ascending by unsigned
+ *   byte, a proper prefix first (std::string::operator<), ties in input order.
+ *   Result == radix_sort::sort on std::string keys: the value path (radix_sort.hpp:528-586 string
+ *   branch, getChar :107-110, bucket 256 first :196-200, std::sort from depth 3 :559-569) for
+ *   stable = 0, the projected path (:1208-1272, std::stable_sort from depth 3 :1241-1255) for
+ *   stable = 1 -- the permutation that sortByIndices (:1111-1154) applies.
+ *   n < 2^32 - 1.  Runs MSD over 7-byte chunks with segment ids (radix-sort_amd/csrc/rsort_strings.hpp). */
+int rs_sort_strings(rs_ctx* ctx, const uint8_t* h_blob, const uint64_t* h_offsets, size_t n,
+                    uint64_t* h_perm, int stable);
+
 /* Library/ABI version: major*10000 + minor*100 + patch. */
 int rs_version(void);
 

@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include "rsort_kernels.hpp"
+#include "rsort_strings.hpp"
 
 namespace {
 
@@ -49,7 +50,7 @@ struct rs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
-  DevBuf alt_keys, alt_vals, desc, ctrl;
+  DevBuf alt_keys, alt_vals, desc, ctrl, strbuf;
   // ctrl layout: [0, 16K) ghist  u64[8][256]; [16K, 32K) gbase u64[8][256];
   //              [32K, 32K+64) tickets u32[16]; [32K+64, 32K+128) error flag (+pad)
   bool profiling = false;
@@ -280,7 +281,7 @@ int rs_ctx_destroy(rs_ctx* c) {
   if (!c) return RS_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->alt_keys, &c->alt_vals, &c->desc, &c->ctrl})
+  for (DevBuf* b : {&c->alt_keys, &c->alt_vals, &c->desc, &c->ctrl, &c->strbuf})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -388,6 +389,96 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
     return rc;
   RS_HIP(c, hipMemcpyAsync(h_keys, dk, kb, hipMemcpyDeviceToHost, c->stream));
   RS_HIP(c, hipMemcpyAsync(h_values, dv, vb, hipMemcpyDeviceToHost, c->stream));
+  return check_kernel_error(c);
+}
+
+
+int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets, size_t n, uint64_t* h_perm, int stable) {
+  (void)stable;   // every pass is stable and level 0 starts from the identity: one code path serves both
+  if (!c) return RS_ERR_ARG;
+  if (n > 0 && (!h_offsets || !h_perm)) return fail(c, RS_ERR_ARG, "null offsets/perm pointer");
+  if (n >= 0xFFFFFFFFull) return fail(c, RS_ERR_ARG, "string sort takes fewer than 2^32 - 1 strings");
+  if (n == 0) return RS_OK;
+  if (n == 1) { h_perm[0] = 0; return RS_OK; }
+  const uint64_t total = h_offsets[n];
+  if (total > 0 && !h_blob) return fail(c, RS_ERR_ARG, "null blob pointer");
+  RS_HIP(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+
+  // carve one device allocation
+  auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t m0 = n;
+  const size_t blocks0 = (m0 + rss::kScanTile - 1) / rss::kScanTile;
+  size_t need = up(total + 8) + up((n + 1) * 8) + 2 * up(m0 * 8) /*keys, keys_alt (also the widened perm)*/ +
+                13 * up(m0 * 4) + up((blocks0 + 2) * 4);
+  int rc;
+  if ((rc = ensure(c, c->strbuf, need)) != RS_OK) return rc;
+  char* p = static_cast<char*>(c->strbuf.p);
+  auto take = [&](size_t b) { char* q = p; p += up(b); return q; };
+  auto* d_blob = reinterpret_cast<uint8_t*>(take(total + 8));
+  auto* d_off = reinterpret_cast<uint64_t*>(take((n + 1) * 8));
+  auto* keys = reinterpret_cast<uint64_t*>(take(m0 * 8));
+  auto* keys_alt = reinterpret_cast<uint64_t*>(take(m0 * 8));
+  uint32_t* u[13];
+  for (auto& q : u) q = reinterpret_cast<uint32_t*>(take(m0 * 4));
+  uint32_t *perm = u[0], *val = u[1], *val_alt = u[2], *seg = u[3], *seg2 = u[4], *seg_alt = u[5], *ids = u[6],
+           *ids2 = u[7], *pos = u[8], *pos2 = u[9], *head = u[10], *scan_a = u[11], *scan_b = u[12];
+  auto* block_sums = reinterpret_cast<uint32_t*>(take((blocks0 + 2) * 4));
+
+  if (total) RS_HIP(c, hipMemcpyAsync(d_blob, h_blob, total, hipMemcpyHostToDevice, s));
+  RS_HIP(c, hipMemcpyAsync(d_off, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
+
+  auto grid = [](size_t m) { return dim3(static_cast<unsigned>((m + rss::kBlock - 1) / rss::kBlock)); };
+  auto scan = [&](const uint32_t* in, size_t m, uint32_t* out, bool inclusive) {
+    unsigned blocks = static_cast<unsigned>((m + rss::kScanTile - 1) / rss::kScanTile);
+    hipLaunchKernelGGL(rss::scan_block_sums_kernel, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums);
+    hipLaunchKernelGGL(rss::scan_spine_kernel, dim3(1), dim3(rss::kBlock), 0, s, block_sums, blocks);
+    if (inclusive) hipLaunchKernelGGL(rss::scan_apply_kernel<true>, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums, out);
+    else hipLaunchKernelGGL(rss::scan_apply_kernel<false>, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums, out);
+    return blocks;
+  };
+
+  size_t m = n;
+  uint32_t* cur_pos = nullptr;      // level 0: position j is slot j
+  uint32_t* cur_seg = nullptr;      // level 0: one segment
+  size_t max_seg = 0;
+  const bool prof = c->profiling;
+  c->profiling = false;             // the per-kernel event slots belong to single sorts
+  for (uint32_t level = 0;; ++level) {
+    const uint32_t mm = static_cast<uint32_t>(m);
+    hipLaunchKernelGGL(rss::iota_kernel, grid(m), dim3(rss::kBlock), 0, s, val, level == 0 ? ids : nullptr, mm);
+    hipLaunchKernelGGL(rss::chunk_keys_kernel, grid(m), dim3(rss::kBlock), 0, s, d_blob, d_off, ids, nullptr, mm, level, keys);
+    if ((rc = sort_device(c, keys, val, keys_alt, val_alt, m, 8, 4, RS_XF_NONE, 0, 64)) != RS_OK) { c->profiling = prof; return rc; }
+    if (level > 0) {
+      hipLaunchKernelGGL(rss::gather_u32_kernel, grid(m), dim3(rss::kBlock), 0, s, cur_seg, val, mm, seg2);
+      int bits = 1;
+      while (bits < 32 && (size_t(1) << bits) <= max_seg) ++bits;
+      if ((rc = sort_device(c, seg2, val, seg_alt, val_alt, m, 4, 4, RS_XF_NONE, 0, bits)) != RS_OK) { c->profiling = prof; return rc; }
+      hipLaunchKernelGGL(rss::chunk_keys_kernel, grid(m), dim3(rss::kBlock), 0, s, d_blob, d_off, ids, val, mm, level, keys);
+    }
+    hipLaunchKernelGGL(rss::gather_u32_kernel, grid(m), dim3(rss::kBlock), 0, s, ids, val, mm, ids2);
+    hipLaunchKernelGGL(rss::write_back_kernel, grid(m), dim3(rss::kBlock), 0, s, ids2, cur_pos, mm, perm);
+    hipLaunchKernelGGL(rss::heads_kernel, grid(m), dim3(rss::kBlock), 0, s, keys, level > 0 ? seg2 : nullptr, mm, head);
+    hipLaunchKernelGGL(rss::unresolved_kernel, grid(m), dim3(rss::kBlock), 0, s, keys, head, mm, val_alt /* open */);
+    scan(head, m, scan_a, true);                       // segment numbers (1-based)
+    unsigned blocks = scan(val_alt, m, scan_b, false); // slots of the unresolved
+    uint32_t open_count = 0;
+    RS_HIP(c, hipMemcpyAsync(&open_count, block_sums + blocks, 4, hipMemcpyDeviceToHost, s));
+    RS_HIP(c, hipStreamSynchronize(s));
+    if (open_count == 0) break;
+    uint32_t* next_pos = cur_pos == pos ? pos2 : pos;
+    hipLaunchKernelGGL(rss::compact_kernel, grid(m), dim3(rss::kBlock), 0, s, val_alt, scan_b, scan_a, ids2, cur_pos, mm,
+                       ids, next_pos, seg);
+    cur_pos = next_pos;
+    cur_seg = seg;
+    max_seg = m;            // segment numbers are < m
+    m = open_count;
+    if (level > (1u << 28)) { c->profiling = prof; return fail(c, RS_ERR_KERNEL, "string sort did not converge"); }
+  }
+  c->profiling = prof;
+  RS_HIP(c, hipGetLastError());
+  hipLaunchKernelGGL(rss::widen_kernel, grid(n), dim3(rss::kBlock), 0, s, perm, static_cast<uint32_t>(n), keys);
+  RS_HIP(c, hipMemcpyAsync(h_perm, keys, n * 8, hipMemcpyDeviceToHost, s));
   return check_kernel_error(c);
 }
 

@@ -105,6 +105,17 @@ class Engine:
         return k, v
 
 
+    def sort_strings_host(self, blob: np.ndarray, offsets: np.ndarray, stable: bool = True):
+        """perm (uint64) such that string perm[i] belongs at position i; string i = blob[offsets[i]:offsets[i+1]]."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        perm = np.empty(n, dtype=np.uint64)
+        self._ck(self.lib.rs_sort_strings(self.h, blob.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), n,
+                                          perm.ctypes.data_as(C.c_void_p), int(stable)))
+        return perm
+
+
 def _transform_of(dtype):
     kind = np.dtype(dtype).kind
     if kind == "f":
