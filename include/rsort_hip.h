@@ -84,6 +84,14 @@ int rs_sort_pairs_device(rs_ctx* ctx, void* d_keys, void* d_values, void* d_alt_
                          void* d_alt_values, size_t n, int key_bytes, int value_bytes,
                          int transform, int begin_bit, int end_bit);
 
+/* rs_digit_histogram_device: counts of the 8-bit digits of the (transformed) keys over
+ *   [begin_bit, end_bit): h_counts[p*256 + d] for pass p = digit at begin_bit + 8p.  Synchronises.
+ *   Result == getCountVector (radix_sort.hpp:155-191) for each digit position.  Used by the
+ *   multi-GPU splitter, where the all-reduced top-digit histogram stands in for the reference's
+ *   partitionRegions fan-out (:210-254). */
+int rs_digit_histogram_device(rs_ctx* ctx, const void* d_keys, size_t n, int key_bytes, int transform,
+                              int begin_bit, int end_bit, uint64_t* h_counts);
+
 /* ---- host-buffer entry points (what include/radix_sort.hpp calls) --------------------------------
  * Same contracts; buffers are host memory; H2D, sort, D2H run on the context's stream and the call
  * returns after the data is back. */

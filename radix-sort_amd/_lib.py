@@ -22,6 +22,7 @@ SYMBOLS = [
     ("rs_ctx_get_profile", _i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     ("rs_sort_keys_device", _i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i]),
     ("rs_sort_pairs_device", _i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i]),
+    ("rs_digit_histogram_device", _i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     ("rs_sort_keys", _i, [_vp, _vp, _sz, _i, _i, _i, _i]),
     ("rs_sort_pairs", _i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i]),
     ("rs_sort_strings", _i, [_vp, _vp, _vp, _sz, _vp, _i]),

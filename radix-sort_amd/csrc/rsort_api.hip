@@ -393,6 +393,36 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
 }
 
 
+int rs_digit_histogram_device(rs_ctx* c, const void* d_keys, size_t n, int key_bytes, int transform, int begin_bit,
+                              int end_bit, uint64_t* h_counts) {
+  int rc = check_args(c, d_keys, n, key_bytes, 0, transform, begin_bit, end_bit);
+  if (rc != RS_OK) return rc;
+  if (!h_counts) return fail(c, RS_ERR_ARG, "null output pointer");
+  const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
+  std::memset(h_counts, 0, sizeof(uint64_t) * 256 * passes);
+  if (n == 0) return RS_OK;
+  RS_HIP(c, hipSetDevice(c->device));
+  if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
+  hipStream_t s = c->stream;
+  char* ctrl = static_cast<char*>(c->ctrl.p);
+  auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);
+  RS_HIP(c, hipMemsetAsync(ghist, 0, sizeof(uint64_t) * 256 * kMaxPasses, s));
+  const uint64_t sign = 1ull << (key_bytes * 8 - 1);
+  const uint64_t all = key_bytes == 8 ? ~0ull : ((1ull << (key_bytes * 8)) - 1ull);
+  rsk::HistArgs h{};
+  h.keys = d_keys; h.ghist = ghist; h.n = n;
+  h.fmask = transform == RS_XF_IEEE ? all : 0;
+  h.smask = transform == RS_XF_NONE ? 0 : sign;
+  h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
+  const size_t per_block = static_cast<size_t>(kHistBlock) * 16 / key_bytes * 4;
+  unsigned hgrid = static_cast<unsigned>(std::min<size_t>((n + per_block - 1) / per_block, 256 * 8));
+  launch_hist(h, key_bytes, std::max(hgrid, 1u), s);
+  RS_HIP(c, hipGetLastError());
+  RS_HIP(c, hipMemcpyAsync(h_counts, ghist, sizeof(uint64_t) * 256 * passes, hipMemcpyDeviceToHost, s));
+  RS_HIP(c, hipStreamSynchronize(s));
+  return RS_OK;
+}
+
 int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets, size_t n, uint64_t* h_perm, int stable) {
   (void)stable;   // every pass is stable and level 0 starts from the identity: one code path serves both
   if (!c) return RS_ERR_ARG;

@@ -70,6 +70,14 @@ class Engine:
                                                C.c_void_p(d_alt_keys or None), C.c_void_p(d_alt_vals or None), n,
                                                key_bytes, value_bytes, transform, begin_bit, end_bit))
 
+    def digit_histogram_ptr(self, d_keys, n, key_bytes, transform, begin_bit, end_bit):
+        """numpy uint64 [passes, 256]: digit counts of the transformed keys over [begin_bit, end_bit)."""
+        passes = (end_bit - begin_bit + 7) // 8
+        out = np.zeros((passes, 256), dtype=np.uint64)
+        self._ck(self.lib.rs_digit_histogram_device(self.h, C.c_void_p(d_keys or None), n, key_bytes, transform, begin_bit,
+                                                    end_bit, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # ---- torch tensors on the engine's device ------------------------------------------------------
     def sort_keys_(self, t, transform, alt=None, begin_bit=0, end_bit=None):
         """In-place sort of a contiguous 1-D device tensor whose element size is the key width."""

@@ -1,0 +1,45 @@
+"""numpy stand-in for radix-sort_amd.dist.HipLocal -- TEST INFRASTRUCTURE: lets the splitter logic and
+the exchange run on CPU tensors under gloo.  The product path never uses it."""
+import numpy as np
+import torch
+
+from cpu_checkers import load_oracle
+
+_U = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}
+
+
+class NumpyLocal:
+    def __init__(self, key_bytes, transform):
+        self.kb, self.xf, self.top = key_bytes, transform, key_bytes * 8
+        self.oracle = load_oracle()
+
+    def _order_bits(self, raw):
+        u = raw.view(_U[self.kb])
+        sign = np.array(1, dtype=u.dtype) << np.array(self.kb * 8 - 1, dtype=u.dtype)
+        if self.xf == 1:
+            return u ^ sign
+        if self.xf == 2:
+            return np.where((u & sign) != 0, ~u, u ^ sign)
+        return u
+
+    def _digit(self, raw, begin_bit, end_bit):
+        return ((self._order_bits(raw) >> np.array(begin_bit, dtype=_U[self.kb])) &
+                np.array((1 << (end_bit - begin_bit)) - 1, dtype=_U[self.kb])).astype(np.int64)
+
+    def empty_like(self, t, n):
+        return torch.empty(n, dtype=t.dtype)
+
+    def histogram(self, t, lo, hi, begin_bit, end_bit):
+        return np.bincount(self._digit(t.numpy()[lo:hi], begin_bit, end_bit), minlength=256).astype(np.int64)
+
+    def partition(self, t, lo, hi, begin_bit, end_bit, scratch):
+        a = t.numpy()
+        a[lo:hi] = a[lo:hi][np.argsort(self._digit(a[lo:hi], begin_bit, end_bit), kind="stable")]
+
+    def sort(self, t, scratch=None):
+        a = t.numpy()
+        a[:] = self.oracle.sort_keys(a.view(_U[self.kb]), 0 if self.xf == 0 else self.xf, mt=True).view(a.dtype) \
+            if self.xf != 2 else self.oracle.sort_keys(a.view({4: np.float32, 8: np.float64}[self.kb]), 2, mt=True).view(a.dtype)
+
+    def synchronize(self):
+        pass

@@ -1,0 +1,88 @@
+"""CPU: the multi-GPU splitter (radix-sort_amd/dist.py) -- planning logic as unit tests, and the whole
+histogram -> split -> all-to-all -> local sort path on 2 and 3 gloo ranks with a numpy local backend."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from radix_sort_amd import dist as rsd
+from radix_sort_amd import shapes
+
+
+def test_plan_is_balanced_and_consistent():
+    rng = np.random.Generator(np.random.PCG64(1))
+    world = 4
+    keys = [rng.integers(0, 1 << 32, 50_000, dtype=np.uint32) for _ in range(world)]
+    l1 = np.stack([np.bincount(k >> 24, minlength=256) for k in keys]).astype(np.int64)
+    refine = rsd.boundary_buckets(l1, world)
+    l2 = {b: np.stack([np.bincount((k[(k >> 24) == b] >> 16) & 255, minlength=256) for k in keys]).astype(np.int64) for b in refine}
+    split = rsd.plan_splits(l1, l2, world)
+    assert split[0] == 0 and split[-1] == 65536 and np.all(np.diff(split) >= 0)
+    counts = rsd.exchange_counts(l1, l2, split, world)
+    allk = np.concatenate(keys)
+    for r in range(world):
+        want = int(((allk >> 16) >= split[r]).sum() - ((allk >> 16) >= split[r + 1]).sum())
+        assert counts[:, r].sum() == want
+        assert abs(want - allk.size / world) <= allk.size / 65536 * 4 + 64      # 16-bit resolution
+    assert counts.sum() == allk.size and np.array_equal(counts.sum(axis=1), [k.size for k in keys])
+
+
+def test_plan_degenerate_inputs():
+    world = 3
+    l1 = np.zeros((world, 256), dtype=np.int64)
+    assert list(rsd.plan_splits(l1, {}, world)) == [0, 0, 0, 65536] or rsd.plan_splits(l1, {}, world)[-1] == 65536
+    l1[:, 7] = 1000                                   # every key in one top-digit bucket
+    refine = rsd.boundary_buckets(l1, world)
+    assert refine == [7]
+    l2 = {7: np.zeros((world, 256), dtype=np.int64)}
+    l2[7][:, 3] = 1000                                # ... and one second digit: cannot be split further
+    split = rsd.plan_splits(l1, l2, world)
+    counts = rsd.exchange_counts(l1, l2, split, world)
+    assert counts.sum() == 3000 and np.all(np.diff(split) >= 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, shape, n_per_rank, outdir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import radix_sort_amd  # noqa: F401
+    from dist_cpu_backend import NumpyLocal
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dt, kb, xf = shapes.KEY_TYPES[name]
+        full = shapes.generate(name, n_per_rank * world + 17, shape)
+        bounds = np.linspace(0, full.size, world + 1).astype(int)
+        bounds[1] += 5 if world > 1 else 0               # ragged shards
+        mine = full[bounds[rank]:bounds[rank + 1]].copy()
+        t = torch.from_numpy(mine.view({1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[kb]))
+        out = rsd.distributed_sort(t, NumpyLocal(kb, xf), rsd.Comm())
+        np.save(os.path.join(outdir, f"out{rank}.npy"), out.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name,shape", [("u64", "randomized"), ("u64", "duplicates"), ("u32", "sorted"),
+                                        ("i64", "nearly_sorted"), ("f64", "randomized"), ("u8", "randomized"),
+                                        ("u32", "reverse_sorted")])
+def test_distributed_sort_gloo(tmp_path, oracle, world, name, shape):
+    n_per_rank = 20_000
+    mp.spawn(_worker, args=(world, _free_port(), name, shape, n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    full = shapes.generate(name, n_per_rank * world + 17, shape)
+    got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(world)])
+    want = oracle.sort_keys(full, xf, mt=True)
+    assert got.tobytes() == want.tobytes()
+    sizes = [np.load(tmp_path / f"out{r}.npy").size for r in range(world)]
+    if shape == "randomized" and kb >= 4:
+        assert max(sizes) - min(sizes) <= full.size // 100 + 64

@@ -1,0 +1,47 @@
+"""GPU (one box, one card): two ranks share GPU 0, local compute through the C-ABI (HipLocal), exchange
+over gloo staged through host memory -- exercises everything of the multi-GPU path except RCCL itself."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from radix_sort_amd import shapes
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, name, shape, n, outdir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import radix_sort_amd as rs
+    from radix_sort_amd import dist as rsd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dt, kb, xf = shapes.KEY_TYPES[name]
+        full = shapes.generate(name, n, shape)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        t = torch.from_numpy(full[lo:hi].view({4: np.int32, 8: np.int64}[kb]).copy()).cuda()
+        eng = rs.Engine(0)
+        out = rsd.distributed_sort(t, rsd.HipLocal(eng, kb, xf), rsd.Comm())
+        np.save(os.path.join(outdir, f"out{rank}.npy"), out.cpu().numpy())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,shape", [("u64", "randomized"), ("u64", "duplicates"), ("f64", "randomized"), ("u32", "sorted")])
+def test_two_ranks_one_gpu(tmp_path, oracle, name, shape):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n, world = 600_001, 2
+    mp.spawn(_worker, args=(world, port, name, shape, n, str(tmp_path)), nprocs=world, join=True)
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(world)])
+    want = oracle.sort_keys(shapes.generate(name, n, shape), xf, mt=True)
+    assert got.tobytes() == want.tobytes()
