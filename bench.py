@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- Gkeys/s of the MI355X sort engine on BASELINE.json's metric.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--n KEYS] [--types u32,u64] [--shapes ...]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--keys KEYS] [--types u32,u64] [--shapes ...]
 
 One "step" = one complete sort (histogram + scan + all onesweep passes) of N keys that are already
 resident in HBM; the pristine input is restored device-to-device OUTSIDE the timed region, as the
@@ -10,7 +10,7 @@ reference's harness copies its vector outside the timer (benchmark.cpp:158-160).
 N = 1 : workload = BASELINE configs[1]: uint32 and uint64, five generator shapes, N = 2^30, LSD
         onesweep on one MI355X.  `value` is the uint32 / randomized row (the case BASELINE's metric is
         quoted on first); every (type, shape) row is in `rows`.
-N > 1 : BASELINE configs[4]: uint64 keys, N/GPU = --n, MSD splitter + all-to-all + local LSD sort
+N > 1 : BASELINE configs[4]: uint64 keys, N/GPU = --keys, MSD splitter + all-to-all + local LSD sort
         (radix-sort_amd/dist.py); `value` = total keys over all ranks / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=1 << 30, help="keys (per GPU when --gpus > 1)")
+    ap.add_argument("--keys", dest="n", type=int, default=1 << 30, help="keys (per GPU when --gpus > 1)")
     ap.add_argument("--types", default="u32,u64")
     ap.add_argument("--shapes", default="randomized,sorted,reverse_sorted,nearly_sorted,duplicates")
     ap.add_argument("--cpu-n", type=int, default=100_000_000)
@@ -157,7 +157,7 @@ def main():
     args.shapes = [s for s in args.shapes.split(",") if s]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.gpus > 1 or os.environ.get("RS_BENCH_FORCE_DIST"):
         from radix_sort_amd import dist_bench
         return dist_bench.main(args)
 

@@ -1,4 +1,4 @@
-"""bench.py's N > 1 leg: BASELINE config 5 -- uint64 keys, --n keys per GPU (default 2^30, i.e. 2^33 on
+"""bench.py's N > 1 leg: BASELINE config 5 -- uint64 keys, --keys keys per GPU (default 2^30, i.e. 2^33 on
 8 GPUs), MSD splitter + RCCL all-to-all over xGMI + local LSD onesweep sort (radix-sort_amd/dist.py).
 
 Launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
@@ -26,74 +26,93 @@ def main(args):
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
-        name = "u64"
-        dt, kb, xf = shapes.KEY_TYPES[name]
-        n = args.n
-        eng = rs.Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-        eng.set_profiling(True)
-        eng.reserve(n + n // 4, kb, 0)
-        local = rsd.HipLocal(eng, kb, xf)
-        comm = rsd.Comm()
-        shape = args.shapes[0] if args.shapes else "randomized"
-        src = shapes.generate_device(name, n, shape, dev, seed=shapes.SEED + rank)
-        if shape in ("sorted", "reverse_sorted", "nearly_sorted"):
-            pass  # every rank holds the same ramp: a worst case for the exchange (all ranks send everywhere)
-        work = torch.empty_like(src)
-
-        times, pass_ms = [], []
-        out = None
-        for it in range(args.warmup + args.steps):
-            work.copy_(src)
-            del out
-            torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            out = rsd.distributed_sort(work, local, comm)
-            torch.cuda.synchronize()
-            dist.barrier()
-            t1 = time.perf_counter()
-            if it >= args.warmup:
-                times.append(t1 - t0)
-                pass_ms.extend(eng.profile()[1:])
-        # max over ranks of the summed step time
-        tsum = torch.tensor([sum(times)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tsum, op=dist.ReduceOp.MAX)
-        sec = float(tsum.item()) / len(times)
-
-        # size-independent parity properties: locally sorted, rank boundaries ordered, count and checksum kept
-        okey = out ^ (-(1 << 63))                       # unsigned order as signed
-        ok_local = bool((okey[1:] >= okey[:-1]).all().item()) if out.numel() > 1 else True
-        edge = torch.stack([okey[0], okey[-1]]) if out.numel() else torch.tensor([2 ** 63 - 1, -(2 ** 63)], device=dev)
-        edges = torch.empty(2 * world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(edges, edge.to(torch.int64))
-        e = edges.cpu().view(world, 2)
-        ok_edges = all(int(e[r][1]) <= int(e[r + 1][0]) for r in range(world - 1))
-        stats = torch.stack([torch.tensor(out.numel(), dtype=torch.int64, device=dev), out.sum(),
-                             torch.tensor(n, dtype=torch.int64, device=dev), src.sum(),
-                             torch.tensor(int(ok_local), dtype=torch.int64, device=dev)])
-        dist.all_reduce(stats)
-        sizes = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(sizes, torch.tensor([out.numel()], dtype=torch.int64, device=dev))
+        # The first type is the headline (same key type as the N = 1 line, so the driver's scaling ratio compares
+        # like with like); the others (uint64 = BASELINE configs[4]) are reported in `rows`.
+        rows = [_run_type(args, name, rank, world, local_rank, dev) for name in args.types]
         if rank == 0:
-            s = stats.cpu().tolist()
-            total = n * world
-            avg_pass = (sum(pass_ms) / len(pass_ms)) * 1e-3 if pass_ms else float("nan")
-            achieved = float(sizes[0].item()) * 2 * kb / avg_pass / 1e9 if pass_ms else None
+            head = rows[0]
             line = {
                 "metric": "Gkeys/s (uint32/uint64, N=2^30) at 1/2/4/8 MI355X; % HBM roofline",
-                "value": total / sec / 1e9, "unit": "Gkeys/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": sec * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": name, "data": "synthetic",
-                "config": {"workload": f"{name} {shape} N={n} keys per GPU ({total} total): MSD splitter + RCCL all-to-all "
-                                       "+ local LSD onesweep (BASELINE configs[4])"},
-                "roofline": {"bound": "hbm", "kernel": f"onesweep_kernel<{name}> (local sort, rank 0)", "achieved": achieved,
-                             "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None,
-                             "whole_job_hbm_frac_per_gpu": n * (kb + 2 * kb * kb) / sec / 1e9 / 8000.0},
-                "parity": {"locally_sorted_all_ranks": s[4] == world, "rank_edges_ordered": ok_edges,
-                           "count_kept": s[0] == s[2], "checksum_kept": s[1] == s[3]},
-                "keys_per_rank_after_exchange": sizes.cpu().tolist(),
+                "value": head["gkeys_s"], "unit": "Gkeys/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": head["ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": head["type"], "data": "synthetic",
+                "config": {"workload": f"{head['type']} {head['shape']} N={args.n} keys per GPU ({args.n * world} total): MSD splitter "
+                                       "+ RCCL all-to-all over xGMI + local LSD onesweep (BASELINE configs[4] pattern; "
+                                       "the uint64 row of `rows` is configs[4] itself)"},
+                "roofline": head.pop("roofline"),
+                "rows": rows,
             }
             print(json.dumps(line))
-        eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def _run_type(args, name, rank, world, local_rank, dev):
+    import torch
+    import torch.distributed as dist
+
+    import radix_sort_amd as rs
+    from radix_sort_amd import dist as rsd
+    from radix_sort_amd import shapes
+
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    n = args.n
+    sign = -(1 << 31) if kb == 4 else -(1 << 63)
+    eng = rs.Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    eng.set_profiling(True)
+    eng.reserve(n + n // 4, kb, 0)
+    local = rsd.HipLocal(eng, kb, xf)
+    comm = rsd.Comm()
+    shape = args.shapes[0] if args.shapes else "randomized"
+    # sorted shapes: every rank holds the same ramp, the worst case for the exchange (everyone sends everywhere)
+    src = shapes.generate_device(name, n, shape, dev, seed=shapes.SEED + rank)
+    work = torch.empty_like(src)
+
+    times, pass_ms = [], []
+    out = None
+    for it in range(args.warmup + args.steps):
+        work.copy_(src)
+        del out
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        out = rsd.distributed_sort(work, local, comm)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        if it >= args.warmup:
+            times.append(t1 - t0)
+            pass_ms.extend(eng.profile()[1:])
+    tsum = torch.tensor([sum(times)], dtype=torch.float64, device=dev)     # max over ranks of the K timed steps
+    dist.all_reduce(tsum, op=dist.ReduceOp.MAX)
+    sec = float(tsum.item()) / len(times)
+
+    # size-independent parity properties: locally sorted, rank boundaries ordered, count and checksum kept
+    okey = (out ^ sign).to(torch.int64)                # unsigned order as signed
+    ok_local = bool((okey[1:] >= okey[:-1]).all().item()) if out.numel() > 1 else True
+    edge = torch.stack([okey[0], okey[-1]]) if out.numel() else torch.tensor([2 ** 63 - 1, -(2 ** 63)], device=dev)
+    edges = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(edges, edge)
+    e = edges.cpu().view(world, 2)
+    ok_edges = all(int(e[r][1]) <= int(e[r + 1][0]) for r in range(world - 1))
+    stats = torch.stack([torch.tensor(out.numel(), dtype=torch.int64, device=dev), out.sum(),
+                         torch.tensor(n, dtype=torch.int64, device=dev), src.sum(),
+                         torch.tensor(int(ok_local), dtype=torch.int64, device=dev)])
+    dist.all_reduce(stats)
+    sizes = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([out.numel()], dtype=torch.int64, device=dev))
+    s = stats.cpu().tolist()
+    total = n * world
+    avg_pass = (sum(pass_ms) / len(pass_ms)) * 1e-3 if pass_ms else None
+    achieved = float(sizes[rank].item()) * 2 * kb / avg_pass / 1e9 if avg_pass else None
+    row = {"type": name, "shape": shape, "n_per_gpu": n, "ms": sec * 1e3, "gkeys_s": total / sec / 1e9,
+           "hbm_frac_per_gpu": n * (kb + 2 * kb * kb) / sec / 1e9 / 8000.0,
+           "parity": {"locally_sorted_all_ranks": s[4] == world, "rank_edges_ordered": ok_edges,
+                      "count_kept": s[0] == s[2], "checksum_kept": s[1] == s[3]},
+           "keys_per_rank_after_exchange": sizes.cpu().tolist(),
+           "roofline": {"bound": "hbm", "kernel": f"onesweep_kernel<{name}> (local sort, rank 0)", "achieved": achieved,
+                        "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None}}
+    del out, work, src
+    eng.close()
+    torch.cuda.empty_cache()
+    return row
