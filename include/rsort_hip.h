@@ -59,6 +59,13 @@ int rs_ctx_reserve(rs_ctx* ctx, size_t n, int key_bytes, int value_bytes);
  * device-resident sort queued since the last call reported an internal fault. */
 int rs_ctx_synchronize(rs_ctx* ctx);
 
+/* Order pre-check (default on): before sorting, one early-exit pass tests whether the keys are already
+ * ascending on the sorted field (then the call returns: isSortedBi radix_sort.hpp:296-297, key::isSorted
+ * :746-769) or -- whole key, no payload -- descending (then they are reversed in place: :298-302).
+ * Costs microseconds on unordered input (plus one host synchronisation).  bench.py times the sort
+ * engine with the check both on and off. */
+int rs_ctx_set_precheck(rs_ctx* ctx, int enabled);
+
 /* Per-kernel timing with HIP events on the context's stream (for bench.py's roofline block).
  * After a sort with profiling on, rs_ctx_get_profile fills ms[0] = histogram+scan,
  * ms[1..passes] = the onesweep passes in order; *count = 1 + passes.  Synchronises the stream. */

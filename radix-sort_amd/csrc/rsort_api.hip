@@ -20,9 +20,16 @@
 namespace {
 
 constexpr int kMaxPasses = 8;
-// Tile geometry of the onesweep pass (overridable at build time for tuning runs).
+// Tile geometry of the onesweep pass (overridable at build time for tuning runs).  Narrow = keys and
+// payload of at most 4 bytes each: 768 threads x 16 keys = 12288-key tiles, two workgroups per CU
+// (measured on uint32, N = 2^30: 512x16 at 3 WG/CU 3.05 ms per pass, 768x16 at 2 WG/CU 2.75 ms -- fewer,
+// larger tiles mean fewer look-back walks per key).  Wide (8-byte keys or payload): 512 x 16, where the
+// 64 KB staging area already limits a CU to two workgroups.
 #ifndef RS_SWEEP_BLOCK
-#define RS_SWEEP_BLOCK 512
+#define RS_SWEEP_BLOCK 768
+#endif
+#ifndef RS_SWEEP_BLOCK_WIDE
+#define RS_SWEEP_BLOCK_WIDE 512
 #endif
 #ifndef RS_SWEEP_ITEMS
 #define RS_SWEEP_ITEMS 16
@@ -30,13 +37,18 @@ constexpr int kMaxPasses = 8;
 #ifndef RS_LOOKBACK
 #define RS_LOOKBACK 8
 #endif
-#ifndef RS_MIN_BLOCKS   // workgroups per CU the register allocator must leave room for (keys of <= 4 bytes, no payload)
-#define RS_MIN_BLOCKS 3
+#ifndef RS_MIN_BLOCKS   // workgroups per CU the register allocator must leave room for
+#define RS_MIN_BLOCKS 2
 #endif
-constexpr int kSweepBlock = RS_SWEEP_BLOCK;
+#ifndef RS_MIN_BLOCKS_WIDE
+#define RS_MIN_BLOCKS_WIDE 1
+#endif
 constexpr int kSweepItems = RS_SWEEP_ITEMS;
+constexpr bool narrow_geometry(int key_bytes, int value_bytes) { return key_bytes <= 4 && value_bytes <= 4; }
+constexpr int sweep_block(int key_bytes, int value_bytes) {
+  return narrow_geometry(key_bytes, value_bytes) ? RS_SWEEP_BLOCK : RS_SWEEP_BLOCK_WIDE;
+}
 constexpr int kHistBlock = 512;
-constexpr size_t kTile = static_cast<size_t>(kSweepBlock) * kSweepItems;
 constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-byte descriptor
 
 struct DevBuf {
@@ -54,6 +66,7 @@ struct rs_ctx {
   // ctrl layout: [0, 16K) ghist  u64[8][256]; [16K, 32K) gbase u64[8][256];
   //              [32K, 32K+64) tickets u32[16]; [32K+64, 32K+128) error flag (+pad)
   bool profiling = false;
+  bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   hipEvent_t ev[kMaxPasses + 2] = {};
   int ev_count = 0;
   std::string err;
@@ -65,7 +78,7 @@ constexpr size_t kCtrlHist = 0;
 constexpr size_t kCtrlBase = kMaxPasses * 256 * 8;
 constexpr size_t kCtrlTicket = 2 * kCtrlBase;
 constexpr size_t kCtrlError = kCtrlTicket + 64;
-constexpr size_t kCtrlBytes = kCtrlError + 64;
+constexpr size_t kCtrlBytes = kCtrlError + 64;   // error word at +0, order-check flags at +32
 
 int fail(rs_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -96,8 +109,13 @@ int ensure(rs_ctx* c, DevBuf& b, size_t bytes) {
   return RS_OK;
 }
 
-size_t tiles_for(size_t n) { return (n + kTile - 1) / kTile; }
-size_t desc_bytes_for(size_t n) { return tiles_for(n) * 256 * (n <= kSmallDescLimit ? 4 : 8); }
+size_t tile_keys(int key_bytes, int value_bytes) { return static_cast<size_t>(sweep_block(key_bytes, value_bytes)) * kSweepItems; }
+size_t tiles_for(size_t n, int key_bytes, int value_bytes) {
+  const size_t t = tile_keys(key_bytes, value_bytes);
+  return (n + t - 1) / t;
+}
+// sized for the smaller (wide) tile so that one reservation serves every geometry
+size_t desc_bytes_for(size_t n) { return tiles_for(n, 8, 8) * 256 * (n <= kSmallDescLimit ? 4 : 8); }
 
 int check_args(rs_ctx* c, const void* keys, size_t n, int key_bytes, int value_bytes, int transform,
                int begin_bit, int end_bit) {
@@ -118,11 +136,11 @@ int check_args(rs_ctx* c, const void* keys, size_t n, int key_bytes, int value_b
 
 template <typename K, typename V, typename D>
 void launch_sweep(const rsk::SweepArgs& a, size_t tiles, hipStream_t s) {
-  // 32 KB of staging per tile admits three workgroups per CU when the registers do (measured: 3.73 ms -> 3.07 ms
-  // per uint32 pass at N = 2^30); wider keys or a payload need the registers more than the third workgroup.
-  constexpr int kMinBlocks = (sizeof(K) <= 4 && std::is_same<V, rsk::NoVal>::value) ? RS_MIN_BLOCKS : 1;
-  hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kSweepBlock, kSweepItems, RS_LOOKBACK, kMinBlocks>),
-                     dim3(static_cast<unsigned>(tiles)), dim3(kSweepBlock), 0, s, a);
+  constexpr int kVal = std::is_same<V, rsk::NoVal>::value ? 0 : static_cast<int>(sizeof(V));
+  constexpr int kBlock = sweep_block(static_cast<int>(sizeof(K)), kVal);
+  constexpr int kMinBlocks = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
+  hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kBlock, kSweepItems, RS_LOOKBACK, kMinBlocks>),
+                     dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0, s, a);
 }
 
 template <typename K, typename V>
@@ -163,13 +181,23 @@ void launch_hist(const rsk::HistArgs& a, int key_bytes, unsigned grid, hipStream
   }
 }
 
+template <typename K>
+void launch_order_k(const rsk::OrderArgs& a, unsigned grid, hipStream_t s) {
+  hipLaunchKernelGGL((rsk::order_check_kernel<K, 256>), dim3(grid), dim3(256), 0, s, a);
+}
+template <typename K>
+void launch_reverse_k(void* keys, size_t n, hipStream_t s) {
+  unsigned grid = static_cast<unsigned>(std::min<size_t>((n / 2 + 255) / 256, 256 * 16));
+  hipLaunchKernelGGL((rsk::reverse_kernel<K>), dim3(std::max(grid, 1u)), dim3(256), 0, s, static_cast<K*>(keys), static_cast<uint64_t>(n));
+}
+
 // The device sort proper.  keys/vals are sorted in place; alt_* are same-size scratch.
 int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_vals, size_t n, int key_bytes,
                 int value_bytes, int transform, int begin_bit, int end_bit) {
   if (n < 2) { c->ev_count = 0; return RS_OK; }
   hipStream_t s = c->stream;
   const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
-  const size_t tiles = tiles_for(n);
+  const size_t tiles = tiles_for(n, key_bytes, value_bytes);
   const bool wide = n > kSmallDescLimit;
   if (tiles > 0x7FFFFFFFull) return fail(c, RS_ERR_ARG, "n too large for one launch");
 
@@ -195,6 +223,38 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   const uint64_t all = key_bytes == 8 ? ~0ull : ((1ull << (key_bytes * 8)) - 1ull);
   const uint64_t fmask = transform == RS_XF_IEEE ? all : 0;
   const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
+
+  // Order pre-check (isSortedBi :269-305 / key::isSorted :746-769): ascending on the sorted field -> nothing to do
+  // (a stable sort of ordered input is the identity); descending, whole key, no payload -> reverse in place.
+  if (c->precheck) {
+    rsk::OrderArgs o{};
+    o.keys = keys; o.flags = error_flag + 8; o.n = n; o.fmask = fmask; o.smask = smask;
+    o.begin_bit = begin_bit; o.bits = end_bit - begin_bit;
+    RS_HIP(c, hipMemsetAsync(o.flags, 0, sizeof(unsigned), s));
+    const unsigned ogrid = static_cast<unsigned>(std::min<size_t>((n + 2047) / 2048, 256 * 8));
+    switch (key_bytes) {
+      case 1: launch_order_k<uint8_t>(o, ogrid, s); break;
+      case 2: launch_order_k<uint16_t>(o, ogrid, s); break;
+      case 4: launch_order_k<uint32_t>(o, ogrid, s); break;
+      default: launch_order_k<uint64_t>(o, ogrid, s); break;
+    }
+    unsigned flags = 3;
+    RS_HIP(c, hipMemcpyAsync(&flags, o.flags, sizeof(flags), hipMemcpyDeviceToHost, s));
+    RS_HIP(c, hipStreamSynchronize(s));
+    const bool whole = begin_bit == 0 && end_bit == key_bytes * 8;
+    if ((flags & 1u) == 0) { c->ev_count = 0; return RS_OK; }
+    if ((flags & 2u) == 0 && whole && value_bytes == 0) {
+      switch (key_bytes) {
+        case 1: launch_reverse_k<uint8_t>(keys, n, s); break;
+        case 2: launch_reverse_k<uint16_t>(keys, n, s); break;
+        case 4: launch_reverse_k<uint32_t>(keys, n, s); break;
+        default: launch_reverse_k<uint64_t>(keys, n, s); break;
+      }
+      RS_HIP(c, hipGetLastError());
+      c->ev_count = 0;
+      return RS_OK;
+    }
+  }
 
   int ev = 0;
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
@@ -313,6 +373,12 @@ int rs_ctx_reserve(rs_ctx* c, size_t n, int key_bytes, int value_bytes) {
 int rs_ctx_synchronize(rs_ctx* c) {
   if (!c) return RS_ERR_ARG;
   return check_kernel_error(c);   // synchronises, then reports a look-back fault of any queued sort
+}
+
+int rs_ctx_set_precheck(rs_ctx* c, int enabled) {
+  if (!c) return RS_ERR_ARG;
+  c->precheck = enabled != 0;
+  return RS_OK;
 }
 
 int rs_ctx_set_profiling(rs_ctx* c, int enabled) {

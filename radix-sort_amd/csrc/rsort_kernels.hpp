@@ -46,6 +46,10 @@ __device__ unsigned long long rs_stamp_buf[16 * 4096];
 #define RS_STAMP(slot) do {} while (0)
 #endif
 
+#ifndef RS_LB_CACHED   // experiment (rejected: stale L2 copies lengthen the walk: 3.08 -> 4.35 ms per u32 pass)
+#define RS_LB_CACHED 0
+#endif
+
 namespace rsk {
 
 constexpr int kRadixBits = 8;      // radix_sort.hpp:32  SHIFT_BITS
@@ -89,6 +93,63 @@ template <typename K> __device__ __forceinline__ unsigned digit_at(K k, int shif
 
 __device__ __forceinline__ unsigned lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// ------------------------------------------------------------------------------------------------
+// 0. order pre-check (isSortedBi, radix_sort.hpp:269-305; key::isSorted :746-769)
+// ------------------------------------------------------------------------------------------------
+// flags bit 0: some neighbour pair descends (input is not ascending); bit 1: some pair ascends (not
+// descending).  Blocks look at the flags before each chunk and stop once both are set, so the check
+// costs microseconds on unordered inputs and one read of the keys on ordered ones -- where it
+// replaces the whole sort, as it does in the reference.
+struct OrderArgs {
+  const void* keys;
+  unsigned* flags;
+  uint64_t n;
+  uint64_t fmask, smask;
+  int begin_bit;
+  int bits;        // end_bit - begin_bit
+};
+
+template <typename K> __device__ __forceinline__ K order_field(K k, const OrderArgs& a) {
+  K t = xf_forward(k, static_cast<K>(a.fmask), static_cast<K>(a.smask));
+  if (a.bits == static_cast<int>(sizeof(K)) * 8) return t;
+  return static_cast<K>((t >> a.begin_bit) & ((static_cast<K>(1) << a.bits) - 1));
+}
+
+template <typename K, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void order_check_kernel(OrderArgs a) {
+  constexpr int ITEMS = 8;
+  const K* keys = static_cast<const K*>(a.keys);
+  const uint64_t chunk = static_cast<uint64_t>(BLOCK) * ITEMS;
+  for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * chunk; base + 1 < a.n; base += static_cast<uint64_t>(gridDim.x) * chunk) {
+    const unsigned seen = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (seen == 3u) return;
+    unsigned f = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      uint64_t j = base + static_cast<uint64_t>(i) * BLOCK + threadIdx.x;
+      if (j + 1 < a.n) {
+        K x = order_field(keys[j], a), y = order_field(keys[j + 1], a);
+        f |= (x > y ? 1u : 0u) | (x < y ? 2u : 0u);
+      }
+    }
+    // set a bit only if this chunk did not already see it set: one word must not take an atomic per wave and chunk
+    if (!(seen & 1u) && __ballot(f & 1u) && (threadIdx.x & 63) == 0) atomicOr(a.flags, 1u);
+    if (!(seen & 2u) && __ballot(f & 2u) && (threadIdx.x & 63) == 0) atomicOr(a.flags, 2u);
+  }
+}
+
+// in-place reversal (std::reverse, radix_sort.hpp:300)
+template <typename K>
+__global__ void reverse_kernel(K* keys, uint64_t n) {
+  uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (; i < n / 2; i += stride) {
+    K x = keys[i], y = keys[n - 1 - i];
+    keys[i] = y;
+    keys[n - 1 - i] = x;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -431,7 +492,15 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
         for (int j = 0; j < LOOKBACK; ++j) {
           long long tt = t - j;
-          w[j] = desc_load(&desc[static_cast<uint64_t>(tt < 0 ? 0 : tt) * kRadix + tid]);
+          const D* p = &desc[static_cast<uint64_t>(tt < 0 ? 0 : tt) * kRadix + tid];
+#if RS_LB_CACHED
+          // Cached (L2-served, L1-bypassing) reads: descriptor states only move forward (none -> aggregate ->
+          // inclusive), so a stale copy in this XCD's L2 can only make the walk longer, never wrong; an entry
+          // that reads "none" is re-polled through the coherent path below.
+          w[j] = __builtin_nontemporal_load(p);
+#else
+          w[j] = desc_load(p);
+#endif
         }
         bool done = false;
         int consumed = 0;
@@ -445,7 +514,24 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
         }
         if (done) break;
         t -= consumed;
+#if RS_LB_CACHED
+        if (consumed < LOOKBACK) {
+          // the entry at t looked unpublished (or stale): poll it coherently until it is there
+          const D* p = &desc[static_cast<uint64_t>(t) * kRadix + tid];
+          D v = desc_load(p);
+          while ((static_cast<unsigned>(v >> Desc<D>::kShift) != a.incl_code) &&
+                 (static_cast<unsigned>(v >> Desc<D>::kShift) != kCodeAgg)) {
+            if (guard.expired(a.error_flag)) { failed = true; break; }
+            v = desc_load(p);
+          }
+          if (failed) break;
+          excl += static_cast<unsigned long long>(v & Desc<D>::kValueMask);
+          if (static_cast<unsigned>(v >> Desc<D>::kShift) == a.incl_code) break;
+          --t;
+        }
+#else
         if (consumed == 0 && guard.expired(a.error_flag)) { failed = true; break; }
+#endif
       }
       if (failed) __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       D word = (static_cast<D>(a.incl_code) << Desc<D>::kShift) |

@@ -47,6 +47,9 @@ class Engine:
     def synchronize(self):
         self._ck(self.lib.rs_ctx_synchronize(self.h))
 
+    def set_precheck(self, on: bool):
+        self._ck(self.lib.rs_ctx_set_precheck(self.h, int(on)))
+
     def set_profiling(self, on: bool):
         self._ck(self.lib.rs_ctx_set_profiling(self.h, int(on)))
 
