@@ -43,7 +43,12 @@ constexpr int kMaxPasses = 8;
 #ifndef RS_MIN_BLOCKS_WIDE
 #define RS_MIN_BLOCKS_WIDE 1
 #endif
-constexpr int kSweepItems = RS_SWEEP_ITEMS;
+#ifndef RS_SWEEP_ITEMS_WIDE
+#define RS_SWEEP_ITEMS_WIDE 16
+#endif
+constexpr int sweep_items(int key_bytes, int value_bytes) {
+  return (key_bytes <= 4 && value_bytes <= 4) ? RS_SWEEP_ITEMS : RS_SWEEP_ITEMS_WIDE;
+}
 constexpr bool narrow_geometry(int key_bytes, int value_bytes) { return key_bytes <= 4 && value_bytes <= 4; }
 constexpr int sweep_block(int key_bytes, int value_bytes) {
   return narrow_geometry(key_bytes, value_bytes) ? RS_SWEEP_BLOCK : RS_SWEEP_BLOCK_WIDE;
@@ -109,7 +114,9 @@ int ensure(rs_ctx* c, DevBuf& b, size_t bytes) {
   return RS_OK;
 }
 
-size_t tile_keys(int key_bytes, int value_bytes) { return static_cast<size_t>(sweep_block(key_bytes, value_bytes)) * kSweepItems; }
+size_t tile_keys(int key_bytes, int value_bytes) {
+  return static_cast<size_t>(sweep_block(key_bytes, value_bytes)) * sweep_items(key_bytes, value_bytes);
+}
 size_t tiles_for(size_t n, int key_bytes, int value_bytes) {
   const size_t t = tile_keys(key_bytes, value_bytes);
   return (n + t - 1) / t;
@@ -138,8 +145,9 @@ template <typename K, typename V, typename D>
 void launch_sweep(const rsk::SweepArgs& a, size_t tiles, hipStream_t s) {
   constexpr int kVal = std::is_same<V, rsk::NoVal>::value ? 0 : static_cast<int>(sizeof(V));
   constexpr int kBlock = sweep_block(static_cast<int>(sizeof(K)), kVal);
+  constexpr int kItems = sweep_items(static_cast<int>(sizeof(K)), kVal);
   constexpr int kMinBlocks = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
-  hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kBlock, kSweepItems, RS_LOOKBACK, kMinBlocks>),
+  hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK, kMinBlocks>),
                      dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0, s, a);
 }
 

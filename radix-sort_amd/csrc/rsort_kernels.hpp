@@ -589,4 +589,5 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   }
 }
 
+
 }  // namespace rsk
