@@ -26,3 +26,32 @@ def test_keys_threshold_crossing(engine, oracle, name):
     dt, kb, xf = shapes.KEY_TYPES[name]
     v = shapes.generate(name, 2000001, "randomized")
     assert engine.sort_keys_host(v, xf).tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes()
+
+
+@pytest.mark.parametrize("name", ["u32", "i32", "f32", "u64", "f64", "u16"])
+@pytest.mark.parametrize("shape", ["sorted", "reverse_sorted", "nearly_sorted"])
+def test_ordered_shapes_without_the_precheck(engine, oracle, name, shape):
+    """The order pre-check answers sorted / reverse inputs by itself; switch it off so the sort engine proper
+    (histogram peel on skewed digits, look-back on one-bucket passes) is what gets compared."""
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    engine.set_precheck(False)
+    try:
+        for n in (1000, 12288, 12289, 100000, 1 << 20):
+            v = shapes.generate(name, n, shape)
+            assert engine.sort_keys_host(v, xf).tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
+    finally:
+        engine.set_precheck(True)
+
+
+def test_precheck_paths(engine, oracle):
+    """ascending -> untouched; descending -> reversed (isSortedBi, radix_sort.hpp:296-302); all equal -> untouched."""
+    for name in ("u32", "i64", "f64"):
+        dt, kb, xf = shapes.KEY_TYPES[name]
+        for shape in ("sorted", "reverse_sorted"):
+            v = shapes.generate(name, 300_000, shape)
+            assert engine.sort_keys_host(v, xf).tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes()
+    v = np.full(100_000, 7, dtype=np.uint32)
+    assert engine.sort_keys_host(v, 0).tobytes() == v.tobytes()
+    # non-strictly descending with ties, and NaNs of both signs in float order
+    v = np.repeat(np.arange(5000, 0, -1, dtype=np.int32), 3)
+    assert engine.sort_keys_host(v, 1).tobytes() == np.sort(v).tobytes()
