@@ -239,13 +239,21 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     o.keys = keys; o.flags = error_flag + 8; o.n = n; o.fmask = fmask; o.smask = smask;
     o.begin_bit = begin_bit; o.bits = end_bit - begin_bit;
     RS_HIP(c, hipMemsetAsync(o.flags, 0, sizeof(unsigned), s));
-    const unsigned ogrid = static_cast<unsigned>(std::min<size_t>((n + 2047) / 2048, 256 * 8));
-    switch (key_bytes) {
-      case 1: launch_order_k<uint8_t>(o, ogrid, s); break;
-      case 2: launch_order_k<uint16_t>(o, ogrid, s); break;
-      case 4: launch_order_k<uint32_t>(o, ogrid, s); break;
-      default: launch_order_k<uint64_t>(o, ogrid, s); break;
-    }
+    // A one-workgroup probe over the head of the array first: on unordered input it sets both flags and the
+    // full-size launch exits at once; without it every workgroup of that launch would start on clear flags and
+    // queue its atomics on the one flag word (measured 0.3 ms at N = 2^30).
+    auto launch_order = [&](const rsk::OrderArgs& oa, unsigned grid) {
+      switch (key_bytes) {
+        case 1: launch_order_k<uint8_t>(oa, grid, s); break;
+        case 2: launch_order_k<uint16_t>(oa, grid, s); break;
+        case 4: launch_order_k<uint32_t>(oa, grid, s); break;
+        default: launch_order_k<uint64_t>(oa, grid, s); break;
+      }
+    };
+    rsk::OrderArgs probe = o;
+    probe.n = std::min<size_t>(n, 65536);
+    launch_order(probe, 1);
+    if (n > probe.n) launch_order(o, static_cast<unsigned>(std::min<size_t>((n + 2047) / 2048, 256 * 8)));
     unsigned flags = 3;
     RS_HIP(c, hipMemcpyAsync(&flags, o.flags, sizeof(flags), hipMemcpyDeviceToHost, s));
     RS_HIP(c, hipStreamSynchronize(s));
