@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -70,6 +71,7 @@ struct rs_ctx {
   DevBuf alt_keys, alt_vals, desc, ctrl, strbuf;
   // ctrl layout: [0, 16K) ghist  u64[8][256]; [16K, 32K) gbase u64[8][256];
   //              [32K, 32K+64) tickets u32[16]; [32K+64, 32K+128) error flag (+pad)
+  bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   hipEvent_t ev[kMaxPasses + 2] = {};
@@ -142,34 +144,38 @@ int check_args(rs_ctx* c, const void* keys, size_t n, int key_bytes, int value_b
 }
 
 template <typename K, typename V, typename D>
-void launch_sweep(const rsk::SweepArgs& a, size_t tiles, hipStream_t s) {
+void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, hipStream_t s) {
   constexpr int kVal = std::is_same<V, rsk::NoVal>::value ? 0 : static_cast<int>(sizeof(V));
   constexpr int kBlock = sweep_block(static_cast<int>(sizeof(K)), kVal);
   constexpr int kItems = sweep_items(static_cast<int>(sizeof(K)), kVal);
   constexpr int kMinBlocks = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
-  hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK, kMinBlocks>),
-                     dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0, s, a);
+  if (atomic_rank)
+    hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK, kMinBlocks, true>),
+                       dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0, s, a);
+  else
+    hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK, kMinBlocks, false>),
+                       dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0, s, a);
 }
 
 template <typename K, typename V>
-void launch_sweep_d(const rsk::SweepArgs& a, size_t tiles, bool wide, hipStream_t s) {
-  if (wide) launch_sweep<K, V, uint64_t>(a, tiles, s);
-  else launch_sweep<K, V, uint32_t>(a, tiles, s);
+void launch_sweep_d(const rsk::SweepArgs& a, size_t tiles, bool wide, bool ar, hipStream_t s) {
+  if (wide) launch_sweep<K, V, uint64_t>(a, tiles, ar, s);
+  else launch_sweep<K, V, uint32_t>(a, tiles, ar, s);
 }
 
 template <typename K>
-void launch_sweep_v(const rsk::SweepArgs& a, size_t tiles, int value_bytes, bool wide, hipStream_t s) {
-  if (value_bytes == 0) launch_sweep_d<K, rsk::NoVal>(a, tiles, wide, s);
-  else if (value_bytes == 4) launch_sweep_d<K, uint32_t>(a, tiles, wide, s);
-  else launch_sweep_d<K, uint64_t>(a, tiles, wide, s);
+void launch_sweep_v(const rsk::SweepArgs& a, size_t tiles, int value_bytes, bool wide, bool ar, hipStream_t s) {
+  if (value_bytes == 0) launch_sweep_d<K, rsk::NoVal>(a, tiles, wide, ar, s);
+  else if (value_bytes == 4) launch_sweep_d<K, uint32_t>(a, tiles, wide, ar, s);
+  else launch_sweep_d<K, uint64_t>(a, tiles, wide, ar, s);
 }
 
-void launch_sweep_k(const rsk::SweepArgs& a, size_t tiles, int key_bytes, int value_bytes, bool wide, hipStream_t s) {
+void launch_sweep_k(const rsk::SweepArgs& a, size_t tiles, int key_bytes, int value_bytes, bool wide, bool ar, hipStream_t s) {
   switch (key_bytes) {
-    case 1: launch_sweep_v<uint8_t>(a, tiles, value_bytes, wide, s); break;
-    case 2: launch_sweep_v<uint16_t>(a, tiles, value_bytes, wide, s); break;
-    case 4: launch_sweep_v<uint32_t>(a, tiles, value_bytes, wide, s); break;
-    default: launch_sweep_v<uint64_t>(a, tiles, value_bytes, wide, s); break;
+    case 1: launch_sweep_v<uint8_t>(a, tiles, value_bytes, wide, ar, s); break;
+    case 2: launch_sweep_v<uint16_t>(a, tiles, value_bytes, wide, ar, s); break;
+    case 4: launch_sweep_v<uint32_t>(a, tiles, value_bytes, wide, ar, s); break;
+    default: launch_sweep_v<uint64_t>(a, tiles, value_bytes, wide, ar, s); break;
   }
 }
 
@@ -298,7 +304,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.shift = begin_bit + p * rsk::kRadixBits;
     a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
     a.incl_code = 2u + (p & 1);
-    launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, s);
+    launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, s);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     std::swap(kin, kout);
     std::swap(vin, vout);
@@ -349,6 +355,24 @@ int rs_ctx_create(rs_ctx** out, int device) {
   c->stream = c->own_stream;
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { rs_ctx_destroy(c); return RS_ERR_HIP; }
+  // Ranking shortcut: usable only if returning LDS adds of one wave instruction are served in lane order.
+  // Probed here on this device (about 2 million lane-operations over six collision patterns); any violation,
+  // or any failure of the probe itself, keeps the ballot-based ranking.
+  {
+    const char* env = std::getenv("RSORT_RANK");      // "ballot" forces the ballot form (tests, A/B timing)
+    unsigned* d_bad = nullptr;
+    unsigned h_bad = 1;
+    if (!(env && std::strcmp(env, "ballot") == 0) && hipMalloc(&d_bad, sizeof(unsigned)) == hipSuccess) {
+      if (hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream) == hipSuccess) {
+        hipLaunchKernelGGL(rsk::lds_order_probe_kernel, dim3(64), dim3(256), 0, c->stream, d_bad, 120);
+        if (hipMemcpyAsync(&h_bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+          h_bad = 1;
+      }
+      (void)hipFree(d_bad);
+    }
+    c->rank_by_lds_atomic = h_bad == 0;
+  }
   *out = c;
   return RS_OK;
 }

@@ -329,6 +329,36 @@ struct SpinGuard {
   }
 };
 
+// Probe for the ranking shortcut: every lane does a returning LDS add on a word chosen by `mode`; a lane counts a
+// violation if the value it got back is not (word before the instruction) + (lower active lanes on the same word).
+__global__ __launch_bounds__(256) void lds_order_probe_kernel(unsigned* violations, int rounds) {
+  __shared__ unsigned hist[4][kRadix];
+  const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  for (unsigned i = lane; i < kRadix; i += kWave) hist[wave][i] = 0;
+  __syncthreads();
+  unsigned bad = 0;
+  for (int r = 0; r < rounds; ++r) {
+    unsigned long long h = (static_cast<unsigned long long>(blockIdx.x) << 40) ^ (static_cast<unsigned long long>(r) << 16) ^ threadIdx.x;
+    h += 0x9E3779B97F4A7C15ull; h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull; h = (h ^ (h >> 27)) * 0x94D049BB133111EBull; h ^= h >> 31;
+    const int mode = r % 6;
+    unsigned d = mode == 0 ? (h & 255u) : mode == 1 ? (h & 3u) : mode == 2 ? 7u : mode == 3 ? (lane >> 2) + (h & 1u)
+               : static_cast<unsigned>((h >> 8) % 37u);
+    const bool active = mode != 5 || ((h >> 20) & 3u) != 0;
+    const unsigned before = hist[wave][d];
+    unsigned dlo, dhi;
+    differ_mask(d, dlo, dhi);
+    const unsigned long long alive = __ballot(active);
+    const unsigned below = __builtin_amdgcn_mbcnt_hi(~dhi & static_cast<unsigned>(alive >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(~dlo & static_cast<unsigned>(alive), 0u));
+    __builtin_amdgcn_wave_barrier();
+    unsigned got = 0;
+    if (active) got = atomicAdd(&hist[wave][d], 1u);
+    __builtin_amdgcn_wave_barrier();
+    if (active && got != before + below) ++bad;
+  }
+  if (bad) atomicAdd(violations, bad);
+}
+
 struct NoVal {};
 
 template <typename K, typename V, typename D, int BLOCK, int ITEMS>
@@ -345,7 +375,7 @@ struct SweepSmem {
   unsigned tile_id;
 };
 
-template <typename K, typename V, typename D, int BLOCK, int ITEMS, int LOOKBACK = 8, int MIN_BLOCKS = 1>
+template <typename K, typename V, typename D, int BLOCK, int ITEMS, int LOOKBACK = 8, int MIN_BLOCKS = 1, bool RANK_BY_LDS_ATOMIC = true>
 __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesweep_kernel(SweepArgs a) {
   using Smem = SweepSmem<K, V, D, BLOCK, ITEMS>;
   constexpr int WAVES = Smem::WAVES;
@@ -411,24 +441,55 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   // register dependency links the rounds.
   unsigned short rank[ITEMS];
   unsigned char dig[ITEMS];
+  if constexpr (RANK_BY_LDS_ATOMIC) {
+    // rank = the value a returning LDS add hands back.  When several lanes of ONE wave instruction hit the same
+    // word, gfx950 serves them in lane order (lds_order_probe_kernel below checks exactly this when a context
+    // is created; the ballot form is used if it ever fails), so equal digits keep lane = key order, and
+    // successive rounds are successive instructions of one wave, which the LDS executes in order.
+    // A digit held by 16 or more lanes is peeled: its first holder adds the population once and the others
+    // derive their rank with mbcnt, so sorted / few-valued inputs do not serialise 64 ways on one word.
 #pragma unroll
-  for (int i = 0; i < ITEMS; ++i) {
-    unsigned d = digit_at(key[i], a.shift, a.bits);
-    dig[i] = static_cast<unsigned char>(d);
-    unsigned dlo, dhi;
-    differ_mask(d, dlo, dhi);
-    unsigned plo = ~dlo, phi = ~dhi;                   // peers: lanes holding the same digit
-    bool ok = true;
-    if (!full) {
-      ok = (seg + i * kWave) < tile_count;
-      unsigned long long alive = __ballot(ok);
-      plo &= static_cast<unsigned>(alive);
-      phi &= static_cast<unsigned>(alive >> 32);
+    for (int i = 0; i < ITEMS; ++i) {
+      unsigned d = digit_at(key[i], a.shift, a.bits);
+      dig[i] = static_cast<unsigned char>(d);
+      unsigned r = 0;
+      if (full || (seg + i * kWave) < tile_count) {
+        unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+        bool mine = d == d0;
+        unsigned long long same = __ballot(mine);
+        if (__popcll(same) >= 16) {
+          unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
+          unsigned ret = 0;
+          if (!mine || below == 0) ret = atomicAdd(&s.whist[wave][d], mine ? static_cast<unsigned>(__popcll(same)) : 1u);
+          unsigned base0 = __builtin_amdgcn_readfirstlane(ret);   // the first active lane holds d0 and is its leader
+          r = mine ? base0 + below : ret;
+        } else {
+          r = atomicAdd(&s.whist[wave][d], 1u);
+        }
+      }
+      rank[i] = static_cast<unsigned short>(r);
     }
-    unsigned below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
-    unsigned before = s.whist[wave][d];
-    if (ok && below == 0) atomicAdd(&s.whist[wave][d], static_cast<unsigned>(__popc(plo) + __popc(phi)));
-    rank[i] = static_cast<unsigned short>(before + below);
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      unsigned d = digit_at(key[i], a.shift, a.bits);
+      dig[i] = static_cast<unsigned char>(d);
+      unsigned dlo, dhi;
+      differ_mask(d, dlo, dhi);
+      unsigned plo = ~dlo, phi = ~dhi;                   // peers: lanes holding the same digit
+      bool ok = true;
+      if (!full) {
+        ok = (seg + i * kWave) < tile_count;
+        unsigned long long alive = __ballot(ok);
+        plo &= static_cast<unsigned>(alive);
+        phi &= static_cast<unsigned>(alive >> 32);
+      }
+      unsigned below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+      unsigned before = s.whist[wave][d];
+      if (ok && below == 0) atomicAdd(&s.whist[wave][d], static_cast<unsigned>(__popc(plo) + __popc(phi)));
+      rank[i] = static_cast<unsigned short>(before + below);
+    }
   }
   __syncthreads();
   RS_STAMP(3);

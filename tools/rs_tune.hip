@@ -70,6 +70,8 @@ int main(int argc, char** argv) {
   if (kb == 4) check<uint32_t><<<2048, 256>>>((uint32_t*)src, n, bad, sums); else check<uint64_t><<<2048, 256>>>((uint64_t*)src, n, bad, sums);
   CK(hipDeviceSynchronize());
   f_prof(c, 1);
+  auto f_pre = (int (*)(rs_ctx*, int))dlsym(h, "rs_ctx_set_precheck");
+  if (f_pre) f_pre(c, getenv("RS_TUNE_PRECHECK") ? 1 : 0);   // time the sort engine proper unless asked otherwise
   std::vector<float> tot, hist, pass;
   for (int it = 0; it < iters + 2; ++it) {
     CK(hipMemcpy(work, src, n * kb, hipMemcpyDeviceToDevice));
@@ -95,7 +97,7 @@ int main(int argc, char** argv) {
   if (f_st) {
     std::vector<unsigned long long> st(16 * 4096);
     f_st(st.data());
-    size_t tiles = (n + 8191) / 8192, cnt = std::min<size_t>(tiles / 64, 4096);
+    size_t tile_keys = (kb <= 4 && vb <= 4) ? 12288 : 8192; size_t tiles = (n + tile_keys - 1) / tile_keys, cnt = std::min<size_t>(tiles / 64, 4096);
     const char* names[] = {"begin->ticket", "ticket->counted", "counted->ranked", "ranked->scanned", "scanned->staged", "staged->lookedback", "lookedback->written"};
     for (int k = 0; k < 7; ++k) {
       std::vector<double> d;
@@ -107,7 +109,7 @@ int main(int argc, char** argv) {
   if (f_st) {
     std::vector<unsigned long long> st(16 * 4096);
     f_st(st.data());
-    size_t tiles = (n + 8191) / 8192, cnt = std::min<size_t>(tiles / 64, 4096);
+    size_t tile_keys = (kb <= 4 && vb <= 4) ? 12288 : 8192; size_t tiles = (n + tile_keys - 1) / tile_keys, cnt = std::min<size_t>(tiles / 64, 4096);
     const char* nm[] = {"lookback trips", "empty trips", "tiles walked"};
     for (int k = 0; k < 3; ++k) {
       std::vector<double> d;
