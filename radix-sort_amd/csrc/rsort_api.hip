@@ -22,12 +22,13 @@ namespace {
 
 constexpr int kMaxPasses = 8;
 // Tile geometry of the onesweep pass (overridable at build time for tuning runs).  Narrow = keys and
-// payload of at most 4 bytes each: 768 threads x 16 keys = 12288-key tiles, two workgroups per CU
-// (measured on uint32, N = 2^30: 512x16 at 3 WG/CU 3.05 ms per pass, 768x16 at 2 WG/CU 2.75 ms -- fewer,
-// larger tiles mean fewer look-back walks per key).  Wide (8-byte keys or payload): 512 x 16, where the
+// payload of at most 4 bytes each: 1024 threads x 16 keys = 16384-key tiles; 64 KB staging + 8 KB of 16-bit
+// wave histograms leave room for two workgroups = 32 waves per CU, and the kernel fits 64 VGPRs.  Measured on
+// uint32, N = 2^30, per pass: 512x16 (3 WG/CU) 3.05 ms, 768x16 (2 WG/CU) 2.59 ms, 1024x16 (2 WG/CU) 2.26 ms --
+// fewer, larger tiles mean fewer look-back walks per key.  Wide (8-byte keys or payload): 512 x 16, where the
 // 64 KB staging area already limits a CU to two workgroups.
 #ifndef RS_SWEEP_BLOCK
-#define RS_SWEEP_BLOCK 768
+#define RS_SWEEP_BLOCK 1024
 #endif
 #ifndef RS_SWEEP_BLOCK_WIDE
 #define RS_SWEEP_BLOCK_WIDE 512

@@ -11,12 +11,14 @@
 //                              the cross-tile prefix is a single-pass chained scan (decoupled
 //                              look-back descriptors, see below)
 //
-// Look-back on MI355X.  The chip retires 30-80 tiles per microsecond while a published word needs
-// ~0.5-1 us to become visible to another CU, so a tile's nearest 20-30 predecessors are still
-// "aggregate only" when it asks.  Measured on the first version (one predecessor per dependent
-// read): 4.2 us of a 15 us tile in look-back.  The walk therefore fetches LOOKBACK predecessors
-// per round trip (independent loads, consumed in order); measured round trip = 0.45 us + 0.075 us
-// per extra row, 24 rows walked at the median.
+// Look-back on MI355X.  The chip retires ~30 tiles per microsecond while a published word needs
+// ~0.5-1 us to become visible to another CU, so a tile's nearest 16-32 predecessors are still
+// "aggregate only" when it asks.  The walk fetches LOOKBACK predecessors per dependent round trip
+// (independent loads, consumed in order).  Measured (stamps build, uint32, 16384-key tiles): median
+// 24 rows walked in 4 round trips of ~1.5 us.  The descriptor reads (coherent, cache-bypassing) are
+// the scarce resource, not the latency alone: spreading a digit's walk over 4 threads covered the
+// 24 rows in 2 round trips and cut the per-tile look-back from 5.9 to 4.6 us, yet the pass got 60 %
+// slower because every tile then read 64 rows.  Fewer, larger tiles are what helps.
 //
 // Memory-model notes (MI355X: 8 XCDs with private, mutually non-coherent L2s):
 //   * look-back descriptors are single 4- or 8-byte words that carry status AND value, written
@@ -44,10 +46,6 @@ __device__ unsigned long long rs_stamp_buf[16 * 4096];
   } while (0)
 #else
 #define RS_STAMP(slot) do {} while (0)
-#endif
-
-#ifndef RS_LB_CACHED   // experiment (rejected: stale L2 copies lengthen the walk: 3.08 -> 4.35 ms per u32 pass)
-#define RS_LB_CACHED 0
 #endif
 
 namespace rsk {
@@ -548,20 +546,18 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
       long long t = static_cast<long long>(tile) - 1;     // next predecessor to consume
       SpinGuard guard;
       bool failed = false;
+#ifdef RS_STAMPS
+      unsigned trips = 0, empty_trips = 0;
+#endif
       while (true) {
+#ifdef RS_STAMPS
+        ++trips;
+#endif
         D w[LOOKBACK];
 #pragma unroll
         for (int j = 0; j < LOOKBACK; ++j) {
           long long tt = t - j;
-          const D* p = &desc[static_cast<uint64_t>(tt < 0 ? 0 : tt) * kRadix + tid];
-#if RS_LB_CACHED
-          // Cached (L2-served, L1-bypassing) reads: descriptor states only move forward (none -> aggregate ->
-          // inclusive), so a stale copy in this XCD's L2 can only make the walk longer, never wrong; an entry
-          // that reads "none" is re-polled through the coherent path below.
-          w[j] = __builtin_nontemporal_load(p);
-#else
-          w[j] = desc_load(p);
-#endif
+          w[j] = desc_load(&desc[static_cast<uint64_t>(tt < 0 ? 0 : tt) * kRadix + tid]);
         }
         bool done = false;
         int consumed = 0;
@@ -575,25 +571,18 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
         }
         if (done) break;
         t -= consumed;
-#if RS_LB_CACHED
-        if (consumed < LOOKBACK) {
-          // the entry at t looked unpublished (or stale): poll it coherently until it is there
-          const D* p = &desc[static_cast<uint64_t>(t) * kRadix + tid];
-          D v = desc_load(p);
-          while ((static_cast<unsigned>(v >> Desc<D>::kShift) != a.incl_code) &&
-                 (static_cast<unsigned>(v >> Desc<D>::kShift) != kCodeAgg)) {
-            if (guard.expired(a.error_flag)) { failed = true; break; }
-            v = desc_load(p);
-          }
-          if (failed) break;
-          excl += static_cast<unsigned long long>(v & Desc<D>::kValueMask);
-          if (static_cast<unsigned>(v >> Desc<D>::kShift) == a.incl_code) break;
-          --t;
-        }
-#else
-        if (consumed == 0 && guard.expired(a.error_flag)) { failed = true; break; }
+#ifdef RS_STAMPS
+        if (consumed == 0) ++empty_trips;
 #endif
+        if (consumed == 0 && guard.expired(a.error_flag)) { failed = true; break; }
       }
+#ifdef RS_STAMPS
+      if (tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096) {
+        rs_stamp_buf[8 * 4096 + (tile >> 6)] = trips;
+        rs_stamp_buf[9 * 4096 + (tile >> 6)] = empty_trips;
+        rs_stamp_buf[10 * 4096 + (tile >> 6)] = static_cast<unsigned long long>(static_cast<long long>(tile) - 1 - t);
+      }
+#endif
       if (failed) __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       D word = (static_cast<D>(a.incl_code) << Desc<D>::kShift) |
                (static_cast<D>(excl + my_count) & Desc<D>::kValueMask);
