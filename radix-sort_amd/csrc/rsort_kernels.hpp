@@ -366,7 +366,10 @@ struct SweepSmem {
   static constexpr bool HAS_VAL = !__is_same(V, NoVal);
   static constexpr size_t kElem = HAS_VAL ? (sizeof(V) > sizeof(K) ? sizeof(V) : sizeof(K)) : sizeof(K);
   alignas(16) unsigned char stage[TILE * kElem];
-  unsigned whist[WAVES][kRadix];    // per wave: running digit counts, later tile_start + wave prefix
+  // per wave: running digit counts, later tile_start + wave prefix.  16-bit cells (a wave holds at most 64 x ITEMS
+  // keys, a tile fewer than 65536), updated two to a 32-bit LDS word: cell d lives in half (d & 1) of word d >> 1.
+  unsigned short whist[WAVES][kRadix];
+  static_assert(TILE < 65536, "16-bit tile-local positions");
   unsigned tile_start[kRadix];      // exclusive scan of the tile's digit counts
   D gofs[kRadix];                   // global offset of the digit's run minus tile_start
   unsigned wave_total[kRadix / kWave];
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #endif
   if (tid == 0) s.tile_id = atomicAdd(a.ticket, 1u);
 #pragma unroll
-  for (int i = 0; i < kRadix / kWave; ++i) s.whist[wave][i * kWave + lane] = 0;
+  for (int i = 0; i < kRadix / 2 / kWave; ++i) reinterpret_cast<unsigned*>(s.whist[wave])[i * kWave + lane] = 0;
   __syncthreads();
 
   const uint64_t tile = s.tile_id;
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   // register dependency links the rounds.
   unsigned short rank[ITEMS];
   unsigned char dig[ITEMS];
+  unsigned* wwords = reinterpret_cast<unsigned*>(s.whist[wave]);   // the wave's cells as 32-bit words
   if constexpr (RANK_BY_LDS_ATOMIC) {
     // rank = the value a returning LDS add hands back.  When several lanes of ONE wave instruction hit the same
     // word, gfx950 serves them in lane order (lds_order_probe_kernel below checks exactly this when a context
@@ -459,11 +463,12 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
           unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
                                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
           unsigned ret = 0;
-          if (!mine || below == 0) ret = atomicAdd(&s.whist[wave][d], mine ? static_cast<unsigned>(__popcll(same)) : 1u);
+          if (!mine || below == 0)
+            ret = (atomicAdd(&wwords[d >> 1], (mine ? static_cast<unsigned>(__popcll(same)) : 1u) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
           unsigned base0 = __builtin_amdgcn_readfirstlane(ret);   // the first active lane holds d0 and is its leader
           r = mine ? base0 + below : ret;
         } else {
-          r = atomicAdd(&s.whist[wave][d], 1u);
+          r = (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
         }
       }
       rank[i] = static_cast<unsigned short>(r);
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
       }
       unsigned below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
       unsigned before = s.whist[wave][d];
-      if (ok && below == 0) atomicAdd(&s.whist[wave][d], static_cast<unsigned>(__popc(plo) + __popc(phi)));
+      if (ok && below == 0) atomicAdd(&wwords[d >> 1], static_cast<unsigned>(__popc(plo) + __popc(phi)) << ((d & 1u) * 16));
       rank[i] = static_cast<unsigned short>(before + below);
     }
   }
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) {
       unsigned c = s.whist[w][tid];
-      s.whist[w][tid] = sum;
+      s.whist[w][tid] = static_cast<unsigned short>(sum);
       sum += c;
     }
   }
