@@ -125,7 +125,7 @@ size_t tiles_for(size_t n, int key_bytes, int value_bytes) {
   return (n + t - 1) / t;
 }
 // sized for the smaller (wide) tile so that one reservation serves every geometry
-size_t desc_bytes_for(size_t n) { return tiles_for(n, 8, 8) * 256 * (n <= kSmallDescLimit ? 4 : 8); }
+size_t desc_bytes_for(size_t n) { return tiles_for(n, 8, 8) * 256 * 8; }   // sized for 8-byte descriptors
 
 int check_args(rs_ctx* c, const void* keys, size_t n, int key_bytes, int value_bytes, int transform,
                int begin_bit, int end_bit) {
@@ -213,7 +213,9 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   hipStream_t s = c->stream;
   const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
   const size_t tiles = tiles_for(n, key_bytes, value_bytes);
-  const bool wide = n > kSmallDescLimit;
+  // RSORT_FORCE_WIDE=1 (tests, A/B timing): 8-byte descriptors and offsets regardless of n
+  static const bool force_wide = [] { const char* e = std::getenv("RSORT_FORCE_WIDE"); return e && e[0] == '1'; }();
+  const bool wide = n > kSmallDescLimit || force_wide;
   if (tiles > 0x7FFFFFFFull) return fail(c, RS_ERR_ARG, "n too large for one launch");
 
   int rc;

@@ -55,3 +55,35 @@ def test_precheck_paths(engine, oracle):
     # non-strictly descending with ties, and NaNs of both signs in float order
     v = np.repeat(np.arange(5000, 0, -1, dtype=np.int32), 3)
     assert engine.sort_keys_host(v, 1).tobytes() == np.sort(v).tobytes()
+
+
+def test_wide_descriptor_path(oracle):
+    """n > 2^30 switches the look-back descriptors and output offsets to 8 bytes; RSORT_FORCE_WIDE=1 takes that
+    path at test sizes (a child process, because the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import radix_sort_amd as rs
+from radix_sort_amd import shapes
+from cpu_checkers import load_oracle
+orc = load_oracle(); eng = rs.Engine(0); eng.set_precheck(False)
+for name in ("u32", "u64", "f64", "i16"):
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    for shape in ("randomized", "duplicates", "sorted"):
+        for n in (1000, 16385, 300001, 1 << 21):
+            v = shapes.generate(name, n, shape)
+            assert eng.sort_keys_host(v, xf).tobytes() == orc.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
+k = shapes.generate("i32", 200001, "duplicates")
+gk, gp = eng.sort_pairs_host(k)
+wk, wp = orc.sort_pairs(k, 1, mt=True)
+assert gk.tobytes() == wk.tobytes() and (gp == wp).all()
+print("WIDE OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSORT_FORCE_WIDE="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "WIDE OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
