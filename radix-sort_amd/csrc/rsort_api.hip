@@ -295,25 +295,45 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase);
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
 
+  // Pass skipping (the device-side counterpart of getMaxLength, radix_sort.hpp:307-370, which lets the reference
+  // drop high bytes that are zero): a pass whose digit is the same for every key is the identity permutation, so it
+  // is not launched.  Needs the counts on the host: 2 KB per pass and one synchronisation.
+  bool live[kMaxPasses];
+  int n_live = 0;
+  {
+    unsigned long long h_hist[kMaxPasses * 256];
+    RS_HIP(c, hipMemcpyAsync(h_hist, ghist, sizeof(unsigned long long) * 256 * passes, hipMemcpyDeviceToHost, s));
+    RS_HIP(c, hipStreamSynchronize(s));
+    for (int p = 0; p < passes; ++p) {
+      live[p] = true;
+      for (int d = 0; d < 256; ++d)
+        if (h_hist[p * 256 + d] == n) { live[p] = false; break; }
+      n_live += live[p];
+    }
+  }
+
   void* kin = keys; void* kout = alt_keys;
   void* vin = vals; void* vout = alt_vals;
+  int done = 0;
   for (int p = 0; p < passes; ++p) {
+    if (!live[p]) continue;
     rsk::SweepArgs a{};
     a.keys_in = kin; a.keys_out = kout; a.vals_in = vin; a.vals_out = vout;
     a.desc = c->desc.p; a.ticket = tickets + p; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
     a.n = n;
-    a.fmask_in = p == 0 ? fmask : 0; a.smask_in = p == 0 ? smask : 0;
-    a.fmask_out = p == passes - 1 ? fmask : 0; a.smask_out = p == passes - 1 ? smask : 0;
+    a.fmask_in = done == 0 ? fmask : 0; a.smask_in = done == 0 ? smask : 0;                    // first launched pass
+    a.fmask_out = done == n_live - 1 ? fmask : 0; a.smask_out = done == n_live - 1 ? smask : 0;  // last launched pass
     a.shift = begin_bit + p * rsk::kRadixBits;
     a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
-    a.incl_code = 2u + (p & 1);
+    a.incl_code = 2u + (done & 1);          // alternates over the LAUNCHED passes (descriptor parity, rsort_kernels.hpp)
     launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, s);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     std::swap(kin, kout);
     std::swap(vin, vout);
+    ++done;
   }
   RS_HIP(c, hipGetLastError());
-  if (passes & 1) {   // result sits in the alternate buffers
+  if (n_live & 1) {   // result sits in the alternate buffers
     RS_HIP(c, hipMemcpyAsync(keys, alt_keys, n * key_bytes, hipMemcpyDeviceToDevice, s));
     if (value_bytes) RS_HIP(c, hipMemcpyAsync(vals, alt_vals, n * value_bytes, hipMemcpyDeviceToDevice, s));
   }

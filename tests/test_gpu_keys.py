@@ -87,3 +87,30 @@ print("WIDE OK")
     env = dict(os.environ, RSORT_FORCE_WIDE="1")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "WIDE OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_pass_skipping_keeps_results(engine, oracle):
+    """Keys that agree on whole bytes (small values, one constant byte, a single distinct value): the passes
+    whose digit is the same for every key are not launched; first/last-pass transforms must still be applied."""
+    rng = np.random.Generator(np.random.PCG64(17))
+    engine.set_precheck(False)
+    try:
+        cases = [
+            ("u64", rng.integers(0, 1000, 200_000, dtype=np.uint64)),                       # only 2 live passes
+            ("u64", (rng.integers(0, 256, 200_000, dtype=np.uint64) << np.uint64(40))),     # one live pass in the middle
+            ("u32", rng.integers(0, 256, 100_000, dtype=np.uint32) | np.uint32(0xAB00CD00)),
+            ("i64", rng.integers(-500, 500, 300_001, dtype=np.int64)),                      # sign flip on a skipped top byte? (top byte varies: 0x00/0xFF)
+            ("i32", rng.integers(0, 100, 50_000, dtype=np.int32)),                          # top byte constant AFTER the sign flip
+            ("f64", rng.integers(1, 200, 100_000).astype(np.float64)),
+            ("f32", -rng.integers(1, 200, 100_000).astype(np.float32)),
+            ("u32", np.full(70_000, 123456, dtype=np.uint32)),                              # no live pass at all
+            ("f64", np.full(70_000, -2.5, dtype=np.float64)),
+        ]
+        for name, v in cases:
+            dt, kb, xf = shapes.KEY_TYPES[name]
+            assert engine.sort_keys_host(v, xf).tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), name
+            wk, wp = oracle.sort_pairs(v, xf, mt=True)
+            gk, gp = engine.sort_pairs_host(v, transform=xf)
+            assert gk.tobytes() == wk.tobytes() and np.array_equal(gp, wp), name
+    finally:
+        engine.set_precheck(True)
