@@ -55,7 +55,7 @@ constexpr bool narrow_geometry(int key_bytes, int value_bytes) { return key_byte
 constexpr int sweep_block(int key_bytes, int value_bytes) {
   return narrow_geometry(key_bytes, value_bytes) ? RS_SWEEP_BLOCK : RS_SWEEP_BLOCK_WIDE;
 }
-constexpr int kHistBlock = 512;
+constexpr int kHistBlock = 1024;
 constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-byte descriptor
 
 struct DevBuf {
@@ -180,6 +180,14 @@ void launch_sweep_k(const rsk::SweepArgs& a, size_t tiles, int key_bytes, int va
   }
 }
 
+// Persistent grid for the histogram: its LDS table is key_bytes x 16 KB (rsk::kHistCols), so one
+// workgroup per CU for 8-byte keys, two otherwise; each workgroup strides over the keys.
+unsigned hist_grid(size_t n, int key_bytes) {
+  const size_t per_block = static_cast<size_t>(kHistBlock) * 16 / key_bytes * 4;
+  const size_t resident = 256 * (key_bytes == 8 ? 1 : 2);
+  return static_cast<unsigned>(std::max<size_t>(std::min<size_t>((n + per_block - 1) / per_block, resident), 1));
+}
+
 template <typename K>
 void launch_hist_k(const rsk::HistArgs& a, unsigned grid, hipStream_t s) {
   const bool whole = a.begin_bit == 0 && a.end_bit == static_cast<int>(sizeof(K)) * 8;
@@ -289,9 +297,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   rsk::HistArgs h{};
   h.keys = keys; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
   h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
-  const size_t per_block = static_cast<size_t>(kHistBlock) * 16 / key_bytes * 4;
-  unsigned hgrid = static_cast<unsigned>(std::min<size_t>((n + per_block - 1) / per_block, 256 * 8));
-  launch_hist(h, key_bytes, std::max(hgrid, 1u), s);
+  launch_hist(h, key_bytes, hist_grid(n, key_bytes), s);
   hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase);
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
 
@@ -543,9 +549,7 @@ int rs_digit_histogram_device(rs_ctx* c, const void* d_keys, size_t n, int key_b
   h.fmask = transform == RS_XF_IEEE ? all : 0;
   h.smask = transform == RS_XF_NONE ? 0 : sign;
   h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
-  const size_t per_block = static_cast<size_t>(kHistBlock) * 16 / key_bytes * 4;
-  unsigned hgrid = static_cast<unsigned>(std::min<size_t>((n + per_block - 1) / per_block, 256 * 8));
-  launch_hist(h, key_bytes, std::max(hgrid, 1u), s);
+  launch_hist(h, key_bytes, hist_grid(n, key_bytes), s);
   RS_HIP(c, hipGetLastError());
   RS_HIP(c, hipMemcpyAsync(h_counts, ghist, sizeof(uint64_t) * 256 * passes, hipMemcpyDeviceToHost, s));
   RS_HIP(c, hipStreamSynchronize(s));

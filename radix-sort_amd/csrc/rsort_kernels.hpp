@@ -163,36 +163,28 @@ struct HistArgs {
   int passes;
 };
 
-// Adds 1 to bins[d] for every active lane.  Skewed inputs (sorted shapes, few distinct values) put
-// most lanes of a wave on ONE LDS word, which the LDS serialises lane by lane: the first lane's
-// digit is peeled off when at least 8 lanes hold it -- its holders are counted by one lane in one
-// add -- and only the other lanes add individually.
-__device__ __forceinline__ void lds_count_digit(unsigned* bins, unsigned d) {
-  unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-  bool mine = d == d0;
-  unsigned long long same = __ballot(mine);
-  if (__popcll(same) >= 8) {           // wave-uniform: worth peeling
-    bool leader = mine && __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
-                                                    __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u)) == 0;
-    if (!mine || leader) atomicAdd(&bins[d], mine ? static_cast<unsigned>(__popcll(same)) : 1u);
-  } else {
-    atomicAdd(&bins[d], 1u);
-  }
-}
+// LDS layout of the per-workgroup histogram: [pass][digit][kHistCols] 32-bit counters, a lane adds
+// to column (lane & 15).  The 32 lanes the LDS serves together then touch 16 different banks with
+// at most two lanes per bank whatever their digits are, which an LDS add absorbs at its issue
+// rate (MI355X_MICROARCH.md, LDS: 2-way costs nothing extra on a 4-cycle store-class instruction).
+// A single [pass][digit] table took ~11 cycles per wave instruction on random digits (bank
+// conflicts) and serialised 64 ways on sorted / few-valued inputs; this layout needs no special
+// case for either.  16 KB per pass: 64 KB for 4-byte keys (two workgroups per CU), 128 KB for 8-byte.
+constexpr int kHistCols = 16;
 
 // WHOLE = the sort covers the whole key in byte-aligned digits (begin_bit 0, end_bit 8*sizeof(K)):
 // every shift is a compile-time constant (one v_bfe_u32 with immediates per digit).
 template <typename K, int MAX_PASSES, bool WHOLE>
-__device__ __forceinline__ void hist_add_key(K k, unsigned* lh, const HistArgs& a) {
+__device__ __forceinline__ void hist_add_key(K k, unsigned* col, const HistArgs& a) {
 #pragma unroll
   for (int p = 0; p < MAX_PASSES; ++p) {
     if constexpr (WHOLE) {
       unsigned w = sizeof(K) == 8 && p >= 4 ? static_cast<unsigned>(static_cast<uint64_t>(k) >> 32) : static_cast<unsigned>(k);
-      lds_count_digit(lh + p * kRadix, (w >> ((p & 3) * 8)) & 0xFFu);
+      atomicAdd(col + (p * kRadix + ((w >> ((p & 3) * 8)) & 0xFFu)) * kHistCols, 1u);
     } else if (p < a.passes) {
       int shift = a.begin_bit + p * kRadixBits;
       int bits = a.end_bit - shift < kRadixBits ? a.end_bit - shift : kRadixBits;
-      lds_count_digit(lh + p * kRadix, digit_at(k, shift, bits));
+      atomicAdd(col + (p * kRadix + digit_at(k, shift, bits)) * kHistCols, 1u);
     }
   }
 }
@@ -201,29 +193,43 @@ template <typename K, int BLOCK, bool WHOLE>
 __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
   constexpr int MAX_PASSES = sizeof(K);
   constexpr int VEC = 16 / sizeof(K);            // 16 bytes per lane per load
-  __shared__ unsigned lh[MAX_PASSES * kRadix];
-  for (int i = threadIdx.x; i < MAX_PASSES * kRadix; i += BLOCK) lh[i] = 0;
+  constexpr int UNROLL = 4;                      // loads in flight per lane
+  __shared__ unsigned lh[MAX_PASSES * kRadix * kHistCols];
+  for (int i = threadIdx.x; i < MAX_PASSES * kRadix * kHistCols; i += BLOCK) lh[i] = 0;
   __syncthreads();
+  unsigned* col = lh + (threadIdx.x & (kHistCols - 1));
 
   const K* keys = static_cast<const K*>(a.keys);
   const K fm = static_cast<K>(a.fmask), sm = static_cast<K>(a.smask);
   const uint64_t nvec = a.n / VEC;
   struct alignas(16) Pack { K v[VEC]; };
   const Pack* vkeys = reinterpret_cast<const Pack*>(keys);
-  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < nvec;
-       i += static_cast<uint64_t>(gridDim.x) * BLOCK) {
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * BLOCK;
+  uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
+    Pack pk[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) pk[u] = vkeys[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(pk[u].v[j], fm, sm), col, a);
+  }
+  for (; i < nvec; i += stride) {
     Pack pk = vkeys[i];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(pk.v[j], fm, sm), lh, a);
+    for (int j = 0; j < VEC; ++j) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(pk.v[j], fm, sm), col, a);
   }
   if (blockIdx.x == 0) {                          // tail (n not a multiple of VEC)
-    uint64_t i = nvec * VEC + threadIdx.x;
-    if (i < a.n) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(keys[i], fm, sm), lh, a);
+    uint64_t t = nvec * VEC + threadIdx.x;
+    if (t < a.n) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(keys[t], fm, sm), col, a);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < a.passes * kRadix; i += BLOCK) {
-    unsigned c = lh[i];
-    if (c) atomicAdd(&a.ghist[i], static_cast<unsigned long long>(c));
+  for (int b = threadIdx.x; b < a.passes * kRadix; b += BLOCK) {
+    unsigned c = 0;
+#pragma unroll
+    for (int j = 0; j < kHistCols; ++j) c += lh[b * kHistCols + ((j + b) & (kHistCols - 1))];
+    if (c) atomicAdd(&a.ghist[b], static_cast<unsigned long long>(c));
   }
 }
 
