@@ -1,0 +1,49 @@
+// scatter_roofline.hip -- what HBM delivers for the onesweep access pattern without any sorting work.
+//   hipcc -O3 --offload-arch=gfx950 tools/scatter_roofline.hip -o tools/scatter_roofline
+// One workgroup per 64 KB tile: reads the tile front to back, writes it as `streams` runs of `run` bytes, run r of
+// tile t going to stream (r % streams) at the position the t-th tile of a uniform-digit sort would write it.
+// streams = 1 is a plain copy; streams = 256, run = 256 is a uint32 onesweep pass on uniform random digits.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+__global__ __launch_bounds__(1024) void scatter_kernel(const uint4* in, uint4* out, unsigned tiles, unsigned streams, unsigned run16 /* 16-byte units per run */) {
+  const unsigned t = blockIdx.x;
+  const unsigned tile16 = 65536 / 16;                       // 4096 uint4 per tile
+  const uint4* src = in + static_cast<size_t>(t) * tile16;
+  const size_t stream16 = static_cast<size_t>(tiles) * tile16 / streams;   // uint4 per stream
+  const unsigned runs_per_stream = tile16 / run16 / streams;                // runs of this tile per stream
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned j = i * 1024 + threadIdx.x;             // uint4 index in the tile
+    const uint4 v = src[j];
+    const unsigned r = j / run16, o = j % run16;
+    const unsigned s = r % streams, k = r / streams;       // stream and the run's index among this tile's runs of that stream
+    out[static_cast<size_t>(s) * stream16 + (static_cast<size_t>(t) * runs_per_stream + k) * run16 + o] = v;
+  }
+}
+
+int main(int argc, char** argv) {
+  const size_t bytes = argc > 1 ? strtoull(argv[1], 0, 10) << 20 : 4096ull << 20;
+  const unsigned tiles = bytes / 65536;
+  uint4 *in, *out;
+  CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, bytes));
+  CK(hipMemset(in, 1, bytes)); CK(hipMemset(out, 0, bytes));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const unsigned cfg[][2] = {{1, 65536}, {16, 4096}, {64, 1024}, {128, 512}, {256, 256}, {512, 128}, {1024, 64}};
+  for (auto& c : cfg) {
+    std::vector<float> ms;
+    for (int it = 0; it < 7; ++it) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(scatter_kernel, dim3(tiles), dim3(1024), 0, 0, in, out, tiles, c[0], c[1] / 16);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float m; CK(hipEventElapsedTime(&m, e0, e1)); if (it >= 2) ms.push_back(m);
+    }
+    std::sort(ms.begin(), ms.end());
+    printf("streams %4u run %6u B : %.3f ms  %.2f TB/s (read+write)\n", c[0], c[1], ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
+  }
+  return 0;
+}
