@@ -201,9 +201,13 @@ __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
 
   const K* keys = static_cast<const K*>(a.keys);
   const K fm = static_cast<K>(a.fmask), sm = static_cast<K>(a.smask);
-  const uint64_t nvec = a.n / VEC;
+  // head: keys before the first 16-byte boundary (the multi-GPU splitter passes sub-range pointers that are only
+  // key-aligned); tail: what is left after the last whole 16-byte pack
+  uint64_t head = ((16u - (reinterpret_cast<uintptr_t>(keys) & 15u)) & 15u) / sizeof(K);
+  if (head > a.n) head = a.n;
+  const uint64_t nvec = (a.n - head) / VEC;
   struct alignas(16) Pack { K v[VEC]; };
-  const Pack* vkeys = reinterpret_cast<const Pack*>(keys);
+  const Pack* vkeys = reinterpret_cast<const Pack*>(keys + head);
   const uint64_t stride = static_cast<uint64_t>(gridDim.x) * BLOCK;
   uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x;
   for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
@@ -220,8 +224,9 @@ __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(pk.v[j], fm, sm), col, a);
   }
-  if (blockIdx.x == 0) {                          // tail (n not a multiple of VEC)
-    uint64_t t = nvec * VEC + threadIdx.x;
+  if (blockIdx.x == 0) {                          // fewer than 2 * VEC keys
+    if (threadIdx.x < head) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(keys[threadIdx.x], fm, sm), col, a);
+    uint64_t t = head + nvec * VEC + threadIdx.x;
     if (t < a.n) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(keys[t], fm, sm), col, a);
   }
   __syncthreads();

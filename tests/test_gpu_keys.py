@@ -114,3 +114,25 @@ def test_pass_skipping_keeps_results(engine, oracle):
             assert gk.tobytes() == wk.tobytes() and np.array_equal(gp, wp), name
     finally:
         engine.set_precheck(True)
+
+
+@pytest.mark.parametrize("name", ["u8", "u16", "i32", "f64"])
+def test_histogram_of_key_aligned_subranges(engine, name):
+    """rs_digit_histogram_device on pointers that are key-aligned but not 16-byte aligned (the multi-GPU splitter
+    passes such sub-ranges), against numpy digit counts of the transformed keys."""
+    import torch
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    v = shapes.generate(name, 50_000, "randomized", seed=5)
+    u = v.view({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[kb]).astype(np.uint64)
+    sign = np.uint64(1) << np.uint64(kb * 8 - 1)
+    if xf == 1:
+        u = u ^ sign
+    elif xf == 2:
+        neg = (u >> np.uint64(kb * 8 - 1)).astype(bool)
+        u = np.where(neg, ~u & np.uint64((1 << (kb * 8)) - 1 if kb < 8 else 0xFFFFFFFFFFFFFFFF), u ^ sign)
+    t = torch.from_numpy(v.view(np.uint8).copy()).cuda()
+    for lo, hi in [(0, 50_000), (1, 50_000), (3, 17), (5, 40_001), (7, 8), (13, 4109)]:
+        h = engine.digit_histogram_ptr(t.data_ptr() + lo * kb, hi - lo, kb, xf, 0, kb * 8)
+        for p in range(kb):
+            want = np.bincount(((u[lo:hi] >> np.uint64(8 * p)) & np.uint64(255)).astype(np.int64), minlength=256)
+            assert (np.asarray(h[p]).astype(np.int64) == want).all(), (name, lo, hi, p)
