@@ -188,6 +188,29 @@ unsigned hist_grid(size_t n, int key_bytes) {
   return static_cast<unsigned>(std::max<size_t>(std::min<size_t>((n + per_block - 1) / per_block, resident), 1));
 }
 
+// Single-workgroup sort of at most one tile (rsk::small_sort_kernel); same geometry table as the sweep.
+template <typename K, typename V>
+void launch_small_kv(const rsk::SmallArgs& a, hipStream_t s) {
+  constexpr int kVal = std::is_same<V, rsk::NoVal>::value ? 0 : static_cast<int>(sizeof(V));
+  constexpr int kBlock = sweep_block(static_cast<int>(sizeof(K)), kVal);
+  constexpr int kItems = sweep_items(static_cast<int>(sizeof(K)), kVal);
+  hipLaunchKernelGGL((rsk::small_sort_kernel<K, V, kBlock, kItems>), dim3(1), dim3(kBlock), 0, s, a);
+}
+template <typename K>
+void launch_small_k(const rsk::SmallArgs& a, int value_bytes, hipStream_t s) {
+  if (value_bytes == 0) launch_small_kv<K, rsk::NoVal>(a, s);
+  else if (value_bytes == 4) launch_small_kv<K, uint32_t>(a, s);
+  else launch_small_kv<K, uint64_t>(a, s);
+}
+void launch_small(const rsk::SmallArgs& a, int key_bytes, int value_bytes, hipStream_t s) {
+  switch (key_bytes) {
+    case 1: launch_small_k<uint8_t>(a, value_bytes, s); break;
+    case 2: launch_small_k<uint16_t>(a, value_bytes, s); break;
+    case 4: launch_small_k<uint32_t>(a, value_bytes, s); break;
+    default: launch_small_k<uint64_t>(a, value_bytes, s); break;
+  }
+}
+
 template <typename K>
 void launch_hist_k(const rsk::HistArgs& a, unsigned grid, hipStream_t s) {
   const bool whole = a.begin_bit == 0 && a.end_bit == static_cast<int>(sizeof(K)) * 8;
@@ -226,6 +249,29 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   const bool wide = n > kSmallDescLimit || force_wide;
   if (tiles > 0x7FFFFFFFull) return fail(c, RS_ERR_ARG, "n too large for one launch");
 
+  const uint64_t sign = 1ull << (key_bytes * 8 - 1);
+  const uint64_t all = key_bytes == 8 ? ~0ull : ((1ull << (key_bytes * 8)) - 1ull);
+  const uint64_t fmask = transform == RS_XF_IEEE ? all : 0;
+  const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
+
+  // Small inputs (at most one tile): one launch of one workgroup does the whole sort in LDS -- no histogram, no
+  // descriptors, no pre-check and no host synchronisation (the reference's own small-input shortcut is the insertion
+  // sort at n <= 100, radix_sort.hpp:372-392; the result of either is the one stable ascending order).
+  // RSORT_SMALL=0 (tests, A/B timing) sends small inputs down the general path instead.
+  static const bool small_path = [] { const char* e = std::getenv("RSORT_SMALL"); return !(e && e[0] == '0'); }();
+  if (small_path && tiles == 1 && c->rank_by_lds_atomic) {
+    int ev = 0;
+    if (c->profiling) { RS_HIP(c, hipEventRecord(c->ev[ev++], s)); RS_HIP(c, hipEventRecord(c->ev[ev++], s)); }
+    rsk::SmallArgs sa{};
+    sa.keys = keys; sa.vals = vals; sa.n = static_cast<unsigned>(n); sa.fmask = fmask; sa.smask = smask;
+    sa.begin_bit = begin_bit; sa.end_bit = end_bit;
+    launch_small(sa, key_bytes, value_bytes, s);
+    RS_HIP(c, hipGetLastError());
+    if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+    c->ev_count = c->profiling ? ev : 0;
+    return RS_OK;
+  }
+
   int rc;
   if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
   if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
@@ -243,11 +289,6 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   auto* gbase = reinterpret_cast<unsigned long long*>(ctrl + kCtrlBase);
   auto* tickets = reinterpret_cast<unsigned*>(ctrl + kCtrlTicket);
   auto* error_flag = reinterpret_cast<unsigned*>(ctrl + kCtrlError);
-
-  const uint64_t sign = 1ull << (key_bytes * 8 - 1);
-  const uint64_t all = key_bytes == 8 ? ~0ull : ((1ull << (key_bytes * 8)) - 1ull);
-  const uint64_t fmask = transform == RS_XF_IEEE ? all : 0;
-  const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
 
   // Order pre-check (isSortedBi :269-305 / key::isSorted :746-769): ascending on the sorted field -> nothing to do
   // (a stable sort of ordered input is the identity); descending, whole key, no payload -> reverse in place.

@@ -656,4 +656,134 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// 4. small inputs: the whole sort in one workgroup
+// ------------------------------------------------------------------------------------------------
+// n <= one tile.  One launch does every pass: keys (and payload) stay in registers / LDS between passes, there is no
+// histogram kernel, no descriptor, no ticket and nothing for the host to wait for.  Each pass is the tile part of
+// onesweep_kernel (rank by returning LDS adds in key order -> scan over digits -> scatter to the staging area), then
+// the keys are read back wave-striped for the next pass.  A pass whose digit is the same for all keys is skipped
+// (getMaxLength's effect, radix_sort.hpp:307-370).  Stable, so it serves the pair sort as well.
+struct SmallArgs {
+  void* keys;          // sorted in place
+  void* vals;          // payload, or null
+  unsigned n;
+  uint64_t fmask, smask;
+  int begin_bit, end_bit;
+};
+
+template <typename K, typename V, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
+  constexpr int WAVES = BLOCK / kWave;
+  constexpr int TILE = BLOCK * ITEMS;
+  constexpr bool HAS_VAL = !__is_same(V, NoVal);
+  static_assert(TILE < 65536 && BLOCK >= kRadix, "16-bit positions; one thread per digit");
+  __shared__ K stage_k[TILE];
+  __shared__ V stage_v[HAS_VAL ? TILE : 1];
+  __shared__ unsigned short whist[WAVES][kRadix];
+  __shared__ unsigned wave_total[kRadix / kWave];
+
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned seg = wave * (kWave * ITEMS) + lane;
+  const unsigned n = a.n;
+  K* gk = static_cast<K*>(a.keys);
+  V* gv = static_cast<V*>(a.vals);
+  const K fm = static_cast<K>(a.fmask), sm = static_cast<K>(a.smask);
+
+  K key[ITEMS];
+  V val[HAS_VAL ? ITEMS : 1];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const unsigned idx = seg + i * kWave;
+    key[i] = idx < n ? xf_forward(gk[idx], fm, sm) : static_cast<K>(0);
+    if constexpr (HAS_VAL) { if (idx < n) val[i] = gv[idx]; }
+  }
+
+  unsigned* wwords = reinterpret_cast<unsigned*>(whist[wave]);
+  for (int shift = a.begin_bit; shift < a.end_bit; shift += kRadixBits) {
+    const int bits = a.end_bit - shift < kRadixBits ? a.end_bit - shift : kRadixBits;
+#pragma unroll
+    for (int i = 0; i < kRadix / 2 / kWave; ++i) wwords[i * kWave + lane] = 0;
+    // rank inside the wave (see onesweep_kernel: lane order inside one returning LDS add, round order inside the wave)
+    unsigned short rank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const unsigned d = digit_at(key[i], shift, bits);
+      unsigned r = 0;
+      if (seg + i * kWave < n) {
+        unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+        bool mine = d == d0;
+        unsigned long long same = __ballot(mine);
+        if (__popcll(same) >= 16) {
+          unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
+          unsigned ret = 0;
+          if (!mine || below == 0)
+            ret = (atomicAdd(&wwords[d >> 1], (mine ? static_cast<unsigned>(__popcll(same)) : 1u) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+          unsigned base0 = __builtin_amdgcn_readfirstlane(ret);
+          r = mine ? base0 + below : ret;
+        } else {
+          r = (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+        }
+      }
+      rank[i] = static_cast<unsigned short>(r);
+    }
+    __syncthreads();
+    // per digit: count over the waves; a digit held by every key makes the pass the identity
+    unsigned my_count = 0, inc = 0;
+    if (tid < kRadix) {
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) my_count += whist[w][tid];
+      unsigned v = my_count;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        unsigned u = __shfl_up(v, off, kWave);
+        if (lane >= static_cast<unsigned>(off)) v += u;
+      }
+      inc = v;
+      if (lane == kWave - 1) wave_total[wave] = v;
+    }
+    if (__syncthreads_or(tid < kRadix && my_count == n)) continue;     // workgroup-uniform
+    if (tid < kRadix) {
+      unsigned before = 0;
+      for (unsigned w = 0; w < wave; ++w) before += wave_total[w];
+      unsigned sum = before + inc - my_count;       // start of the digit's run, then + the waves before each wave
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        unsigned c = whist[w][tid];
+        whist[w][tid] = static_cast<unsigned short>(sum);
+        sum += c;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (seg + i * kWave < n) {
+        const unsigned pos = whist[wave][digit_at(key[i], shift, bits)] + rank[i];
+        stage_k[pos] = key[i];
+        if constexpr (HAS_VAL) stage_v[pos] = val[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const unsigned idx = seg + i * kWave;
+      if (idx < n) {
+        key[i] = stage_k[idx];
+        if constexpr (HAS_VAL) val[i] = stage_v[idx];
+      }
+    }
+    // no barrier: the next pass writes the staging area only behind its own two barriers, and each wave zeroes and
+    // fills only its own histogram row before the first of them
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const unsigned idx = seg + i * kWave;
+    if (idx < n) {
+      gk[idx] = xf_inverse(key[i], fm, sm);
+      if constexpr (HAS_VAL) gv[idx] = val[i];
+    }
+  }
+}
+
 }  // namespace rsk

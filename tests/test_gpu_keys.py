@@ -136,3 +136,60 @@ def test_histogram_of_key_aligned_subranges(engine, name):
         for p in range(kb):
             want = np.bincount(((u[lo:hi] >> np.uint64(8 * p)) & np.uint64(255)).astype(np.int64), minlength=256)
             assert (np.asarray(h[p]).astype(np.int64) == want).all(), (name, lo, hi, p)
+
+
+def test_small_inputs_down_the_general_path(oracle):
+    """Inputs of at most one tile normally take rsk::small_sort_kernel (one workgroup, everything in LDS); with
+    RSORT_SMALL=0 they go down the general path (histogram, tickets, look-back) instead, which must agree too.
+    A child process, because the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import radix_sort_amd as rs
+from radix_sort_amd import shapes
+from cpu_checkers import load_oracle
+orc = load_oracle(); eng = rs.Engine(0)
+for name in ("u8", "i16", "u32", "i64", "f32", "f64"):
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    for shape in ("randomized", "duplicates", "reverse_sorted"):
+        for n in (2, 3, 100, 101, 1000, 8191, 8192, 16384):
+            v = shapes.generate(name, n, shape)
+            assert eng.sort_keys_host(v, xf).tobytes() == orc.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
+    k = shapes.generate(name, 5000, "duplicates")
+    gk, gp = eng.sort_pairs_host(k, transform=xf)
+    wk, wp = orc.sort_pairs(k, xf, mt=True)
+    assert gk.tobytes() == wk.tobytes() and (gp == wp).all(), name
+print("GENERAL OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSORT_SMALL="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "GENERAL OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("name", list(shapes.KEY_TYPES))
+def test_small_kernel_sizes_and_bit_ranges(engine, oracle, name):
+    """The single-workgroup kernel at its edges: every size class up to one full tile, partial bit ranges, stable pairs."""
+    import torch
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    tile = 16384 if kb <= 4 else 8192
+    for n in (2, 63, 64, 65, 1023, 1024, 1025, tile - 1, tile):
+        for shape in ("randomized", "duplicates", "nearly_sorted"):
+            v = shapes.generate(name, n, shape, seed=n)
+            assert engine.sort_keys_host(v, xf).tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
+        k = shapes.generate(name, n, "duplicates", seed=n + 1)
+        gk, gp = engine.sort_pairs_host(k, transform=xf)
+        wk, wp = oracle.sort_pairs(k, xf, mt=True)
+        assert gk.tobytes() == wk.tobytes() and np.array_equal(gp, wp), (name, n)
+    if xf == 0 and kb >= 2:                         # a bit range inside the key: stable on the selected field only
+        v = shapes.generate(name, 5000, "randomized", seed=3)
+        t = torch.from_numpy(v.view(np.uint8).copy()).cuda()
+        engine.sort_keys_ptr(t.data_ptr(), v.size, kb, 0, None, 4, kb * 8 - 3)
+        engine.synchronize()
+        field = (v.astype(np.uint64) >> np.uint64(4)) & np.uint64((1 << (kb * 8 - 7)) - 1)
+        want = v[np.argsort(field, kind="stable")]
+        assert t.cpu().numpy().tobytes() == want.tobytes(), name
