@@ -125,14 +125,18 @@ class Comm:
         return out.cpu().numpy().reshape((self.world,) + tuple(np.shape(table)))
 
     def all_to_all(self, send, send_counts, recv_counts, recv):
-        """Variable all-to-all of a 1-D tensor; with gloo the payload is staged through host memory."""
-        ins, outs = [int(x) for x in send_counts], [int(x) for x in recv_counts]
+        """Variable all-to-all of a 1-D tensor; with gloo the payload is staged through host memory.
+        Elements travel as bytes: neither RCCL nor gloo takes every key width (16-bit integers)."""
+        import torch
+        es = send.element_size()
+        ins, outs = [int(x) * es for x in send_counts], [int(x) * es for x in recv_counts]
+        sb, rb = send.view(torch.uint8), recv.view(torch.uint8)
         if self.backend == "nccl" or not send.is_cuda:
-            self.dist.all_to_all_single(recv, send, output_split_sizes=outs, input_split_sizes=ins, group=self.group)
+            self.dist.all_to_all_single(rb, sb, output_split_sizes=outs, input_split_sizes=ins, group=self.group)
         else:
-            r = recv.cpu()
-            self.dist.all_to_all_single(r, send.cpu(), output_split_sizes=outs, input_split_sizes=ins, group=self.group)
-            recv.copy_(r)
+            r = rb.cpu()
+            self.dist.all_to_all_single(r, sb.cpu(), output_split_sizes=outs, input_split_sizes=ins, group=self.group)
+            rb.copy_(r)
         return recv
 
 
@@ -156,16 +160,30 @@ class HipLocal:
         h = self.eng.digit_histogram_ptr(t.data_ptr() + lo * self.kb, hi - lo, self.kb, self.xf, begin_bit, end_bit)
         return h[0].astype(np.int64)
 
-    def partition(self, t, lo, hi, begin_bit, end_bit, scratch):
-        """Stable in-place partition of t[lo:hi] by the digit at [begin_bit, end_bit) of the transformed key."""
-        if hi - lo > 1:
+    def partition(self, t, lo, hi, begin_bit, end_bit, scratch, vals=None, vscratch=None):
+        """Stable in-place partition of t[lo:hi] (and of vals[lo:hi] with it) by the digit at [begin_bit, end_bit)
+        of the transformed key."""
+        if hi - lo <= 1:
+            return
+        if vals is None:
             self.eng.sort_keys_ptr(t.data_ptr() + lo * self.kb, hi - lo, self.kb, self.xf,
                                    scratch.data_ptr() if scratch is not None else None, begin_bit, end_bit)
+        else:
+            vb = vals.element_size()
+            self.eng.sort_pairs_ptr(t.data_ptr() + lo * self.kb, vals.data_ptr() + lo * vb, hi - lo, self.kb, vb, self.xf,
+                                    scratch.data_ptr() if scratch is not None else None,
+                                    vscratch.data_ptr() if vscratch is not None else None, begin_bit, end_bit)
 
-    def sort(self, t, scratch=None):
-        if t.numel() > 1:
-            self.eng.sort_keys_ptr(t.data_ptr(), t.numel(), self.kb, self.xf,
-                                   scratch.data_ptr() if scratch is not None and scratch.numel() >= t.numel() else None)
+    def sort(self, t, scratch=None, vals=None, vscratch=None):
+        n = t.numel()
+        if n <= 1:
+            return
+        ks = scratch.data_ptr() if scratch is not None and scratch.numel() >= n else None
+        if vals is None:
+            self.eng.sort_keys_ptr(t.data_ptr(), n, self.kb, self.xf, ks)
+        else:
+            vs = vscratch.data_ptr() if vscratch is not None and vscratch.numel() >= n else None
+            self.eng.sort_pairs_ptr(t.data_ptr(), vals.data_ptr(), n, self.kb, vals.element_size(), self.xf, ks, vs)
 
     def synchronize(self):
         self.eng.synchronize()
@@ -174,24 +192,31 @@ class HipLocal:
 # ---------------------------------------------------------------------------------------------
 # the distributed sort
 # ---------------------------------------------------------------------------------------------
-def distributed_sort(keys, local, comm: Comm):
+def distributed_sort(keys, local, comm: Comm, values=None):
     """keys: this rank's 1-D tensor of raw key bits (int32 / int64 ...).  Returns this rank's slice of
-    the globally sorted sequence (a new tensor); `keys` is used as scratch and is clobbered."""
+    the globally sorted sequence (a new tensor); `keys` is used as scratch and is clobbered.
+
+    values: optional 1-D payload tensor (4- or 8-byte elements) that travels with the keys; the result is then
+    (keys, values) and the sort is STABLE over the concatenation of the ranks' inputs in rank order -- equal keys keep
+    (source rank, position) order: every partition pass is stable, a 16-bit split never separates equal keys, the
+    exchange delivers the sources' pieces in rank order and the final local sort is stable.  With values = global
+    indices this is the permutation the reference's projected sort applies (radix_sort.hpp:1111-1154)."""
     world = comm.world
     n = keys.numel()
     if world == 1:
-        local.sort(keys)
+        local.sort(keys, None, values, None)
         local.synchronize()
-        return keys
+        return keys if values is None else (keys, values)
     top = local.top
     scratch = local.empty_like(keys, n)
+    vscratch = local.empty_like(values, n) if values is not None else None
 
     # 1-2. top-digit histogram, all-gathered
     h1 = local.histogram(keys, 0, n, top - DIGIT, top)
     level1_all = comm.all_gather_table(h1, keys.device)                    # [G, 256]
 
     # 4a. local MSD partition on the top digit (independent of the other ranks' counts)
-    local.partition(keys, 0, n, top - DIGIT, top, scratch)
+    local.partition(keys, 0, n, top - DIGIT, top, scratch, values, vscratch)
 
     # 3. refine the buckets that hold a quantile; 4b. partition those buckets on the second digit
     refine = boundary_buckets(level1_all, world) if top >= 2 * DIGIT else []
@@ -202,7 +227,7 @@ def distributed_sort(keys, local, comm: Comm):
         for k, b in enumerate(refine):
             lo, hi = int(offs[b]), int(offs[b + 1])
             mine[k] = local.histogram(keys, lo, hi, top - 2 * DIGIT, top - DIGIT)
-            local.partition(keys, lo, hi, top - 2 * DIGIT, top - DIGIT, scratch)
+            local.partition(keys, lo, hi, top - 2 * DIGIT, top - DIGIT, scratch, values, vscratch)
         gathered = comm.all_gather_table(mine, keys.device)                # [G, len(refine), 256]
         for k, b in enumerate(refine):
             level2_all[b] = gathered[:, k, :]
@@ -214,8 +239,12 @@ def distributed_sort(keys, local, comm: Comm):
     local.synchronize()
     recv = local.empty_like(keys, int(recv_counts.sum()))
     comm.all_to_all(keys, send_counts, recv_counts, recv)
+    vrecv = None
+    if values is not None:
+        vrecv = local.empty_like(values, int(recv_counts.sum()))
+        comm.all_to_all(values, send_counts, recv_counts, vrecv)
 
     # 6. local LSD sort of the received range
-    local.sort(recv, scratch)
+    local.sort(recv, scratch, vrecv, vscratch)
     local.synchronize()
-    return recv
+    return recv if values is None else (recv, vrecv)

@@ -32,14 +32,26 @@ class NumpyLocal:
     def histogram(self, t, lo, hi, begin_bit, end_bit):
         return np.bincount(self._digit(t.numpy()[lo:hi], begin_bit, end_bit), minlength=256).astype(np.int64)
 
-    def partition(self, t, lo, hi, begin_bit, end_bit, scratch):
+    def partition(self, t, lo, hi, begin_bit, end_bit, scratch, vals=None, vscratch=None):
         a = t.numpy()
-        a[lo:hi] = a[lo:hi][np.argsort(self._digit(a[lo:hi], begin_bit, end_bit), kind="stable")]
+        order = np.argsort(self._digit(a[lo:hi], begin_bit, end_bit), kind="stable")
+        a[lo:hi] = a[lo:hi][order]
+        if vals is not None:
+            v = vals.numpy()
+            v[lo:hi] = v[lo:hi][order]
 
-    def sort(self, t, scratch=None):
+    def _typed(self, a):
+        return a.view({4: np.float32, 8: np.float64}[self.kb]) if self.xf == 2 else a.view(_U[self.kb])
+
+    def sort(self, t, scratch=None, vals=None, vscratch=None):
         a = t.numpy()
-        a[:] = self.oracle.sort_keys(a.view(_U[self.kb]), 0 if self.xf == 0 else self.xf, mt=True).view(a.dtype) \
-            if self.xf != 2 else self.oracle.sort_keys(a.view({4: np.float32, 8: np.float64}[self.kb]), 2, mt=True).view(a.dtype)
+        if vals is None:
+            a[:] = self.oracle.sort_keys(self._typed(a), self.xf, mt=True).view(a.dtype)
+        else:
+            k, perm = self.oracle.sort_pairs(self._typed(a), self.xf, mt=True)     # stable; perm = source positions
+            v = vals.numpy()
+            v[:] = v[perm.astype(np.int64)]
+            a[:] = k.view(a.dtype)
 
     def synchronize(self):
         pass

@@ -86,3 +86,40 @@ def test_distributed_sort_gloo(tmp_path, oracle, world, name, shape):
     sizes = [np.load(tmp_path / f"out{r}.npy").size for r in range(world)]
     if shape == "randomized" and kb >= 4:
         assert max(sizes) - min(sizes) <= full.size // 100 + 64
+
+
+def _pair_worker(rank, world, port, name, shape, n_per_rank, outdir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import radix_sort_amd  # noqa: F401
+    from dist_cpu_backend import NumpyLocal
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dt, kb, xf = shapes.KEY_TYPES[name]
+        full = shapes.generate(name, n_per_rank * world + 17, shape)
+        bounds = np.linspace(0, full.size, world + 1).astype(int)
+        bounds[1] += 5
+        mine = full[bounds[rank]:bounds[rank + 1]].copy()
+        t = torch.from_numpy(mine.view({1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[kb]))
+        idx = torch.arange(bounds[rank], bounds[rank + 1], dtype=torch.int64)       # global positions as payload
+        k, v = rsd.distributed_sort(t, NumpyLocal(kb, xf), rsd.Comm(), values=idx)
+        np.save(os.path.join(outdir, f"k{rank}.npy"), k.numpy())
+        np.save(os.path.join(outdir, f"v{rank}.npy"), v.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name,shape", [("u64", "duplicates"), ("i32", "duplicates"), ("f64", "randomized"), ("u16", "randomized")])
+def test_distributed_pairs_are_stable_gloo(tmp_path, oracle, world, name, shape):
+    """Keys + payload across ranks: the payload (global input positions) must come back as the reference's stable
+    permutation (key path, radix_sort.hpp:1160-1206 / sortByIndices :1111-1154)."""
+    n_per_rank = 15_000
+    mp.spawn(_pair_worker, args=(world, _free_port(), name, shape, n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    full = shapes.generate(name, n_per_rank * world + 17, shape)
+    gk = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
+    gv = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)])
+    wk, wp = oracle.sort_pairs(full, xf, mt=True)
+    assert gk.tobytes() == wk.tobytes()
+    assert np.array_equal(gv.astype(np.uint64), wp.astype(np.uint64))

@@ -45,3 +45,39 @@ def test_two_ranks_one_gpu(tmp_path, oracle, name, shape):
     got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(world)])
     want = oracle.sort_keys(shapes.generate(name, n, shape), xf, mt=True)
     assert got.tobytes() == want.tobytes()
+
+
+def _pair_worker(rank, world, port, name, shape, n, outdir):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import radix_sort_amd as rs
+    from radix_sort_amd import dist as rsd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dt, kb, xf = shapes.KEY_TYPES[name]
+        full = shapes.generate(name, n, shape)
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        t = torch.from_numpy(full[lo:hi].view({4: np.int32, 8: np.int64}[kb]).copy()).cuda()
+        idx = torch.arange(lo, hi, dtype=torch.int64 if kb == 8 else torch.int32).cuda()
+        eng = rs.Engine(0)
+        k, v = rsd.distributed_sort(t, rsd.HipLocal(eng, kb, xf), rsd.Comm(), values=idx)
+        np.save(os.path.join(outdir, f"k{rank}.npy"), k.cpu().numpy())
+        np.save(os.path.join(outdir, f"v{rank}.npy"), v.cpu().numpy())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,shape", [("u64", "duplicates"), ("i32", "duplicates"), ("f64", "randomized")])
+def test_two_ranks_one_gpu_stable_pairs(tmp_path, oracle, name, shape):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n, world = 400_001, 2
+    mp.spawn(_pair_worker, args=(world, port, name, shape, n, str(tmp_path)), nprocs=world, join=True)
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    gk = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
+    gv = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)])
+    wk, wp = oracle.sort_pairs(shapes.generate(name, n, shape), xf, mt=True)
+    assert gk.tobytes() == wk.tobytes()
+    assert np.array_equal(gv.astype(np.uint64), wp.astype(np.uint64))
