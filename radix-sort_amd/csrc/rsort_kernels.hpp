@@ -461,28 +461,54 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     // successive rounds are successive instructions of one wave, which the LDS executes in order.
     // A digit held by 16 or more lanes is peeled: its first holder adds the population once and the others
     // derive their rank with mbcnt, so sorted / few-valued inputs do not serialise 64 ways on one word.
+    // The ranking is issue-bound (8 waves per SIMD run this loop together), so the test "is this round worth peeling"
+    // is made once per group of four rounds, on the group's first round: random digits then pay 9 instructions per
+    // key instead of 15.  A group that is not peeled but should have been is still ranked correctly, only slower.
+    static_assert(ITEMS % 4 == 0, "rounds are ranked in groups of four");
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      unsigned d = digit_at(key[i], a.shift, a.bits);
-      dig[i] = static_cast<unsigned char>(d);
-      unsigned r = 0;
-      if (full || (seg + i * kWave) < tile_count) {
-        unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-        bool mine = d == d0;
-        unsigned long long same = __ballot(mine);
-        if (__popcll(same) >= 16) {
-          unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
-          unsigned ret = 0;
-          if (!mine || below == 0)
-            ret = (atomicAdd(&wwords[d >> 1], (mine ? static_cast<unsigned>(__popcll(same)) : 1u) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
-          unsigned base0 = __builtin_amdgcn_readfirstlane(ret);   // the first active lane holds d0 and is its leader
-          r = mine ? base0 + below : ret;
-        } else {
-          r = (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+    for (int g = 0; g < ITEMS; g += 4) {
+      bool peel_group = false;
+      {
+        const unsigned d = digit_at(key[g], a.shift, a.bits);
+        if (full || (seg + g * kWave) < tile_count)
+          peel_group = __popcll(__ballot(d == static_cast<unsigned>(__builtin_amdgcn_readfirstlane(d)))) >= 16;
+        peel_group = __builtin_amdgcn_readfirstlane(peel_group ? 1 : 0) != 0;   // lane 0 is valid whenever any lane is
+      }
+      if (peel_group) {
+#pragma unroll
+        for (int i = g; i < g + 4; ++i) {
+          unsigned d = digit_at(key[i], a.shift, a.bits);
+          dig[i] = static_cast<unsigned char>(d);
+          unsigned r = 0;
+          if (full || (seg + i * kWave) < tile_count) {
+            unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+            bool mine = d == d0;
+            unsigned long long same = __ballot(mine);
+            if (__popcll(same) >= 16) {
+              unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
+              unsigned ret = 0;
+              if (!mine || below == 0)
+                ret = (atomicAdd(&wwords[d >> 1], (mine ? static_cast<unsigned>(__popcll(same)) : 1u) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+              unsigned base0 = __builtin_amdgcn_readfirstlane(ret);   // the first active lane holds d0 and is its leader
+              r = mine ? base0 + below : ret;
+            } else {
+              r = (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+            }
+          }
+          rank[i] = static_cast<unsigned short>(r);
+        }
+      } else {
+#pragma unroll
+        for (int i = g; i < g + 4; ++i) {
+          unsigned d = digit_at(key[i], a.shift, a.bits);
+          dig[i] = static_cast<unsigned char>(d);
+          unsigned r = 0;
+          if (full || (seg + i * kWave) < tile_count)
+            r = (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+          rank[i] = static_cast<unsigned short>(r);
         }
       }
-      rank[i] = static_cast<unsigned short>(r);
     }
   } else {
 #pragma unroll
