@@ -370,6 +370,13 @@ __global__ __launch_bounds__(256) void lds_order_probe_kernel(unsigned* violatio
 
 struct NoVal {};
 
+// Staging-area swizzle.  A key staged at tile-local sorted position p lives at element p ^ ((p >> 6) & 31).  On
+// ordered inputs every digit's run in a tile has (nearly) the same power-of-two length, so the lanes of one staging
+// store -- same rank, different digits -- would otherwise all fall on one LDS bank (measured: 4.4x the bank-conflict
+// cycles of random input, staging 5.3 us instead of 1.4).  The XOR only permutes positions inside aligned groups of
+// 32, so the write-out, which reads aligned runs of consecutive positions, stays conflict-free.
+__device__ __forceinline__ unsigned stage_swizzle(unsigned p) { return p ^ ((p >> 6) & 31u); }
+
 template <typename K, typename V, typename D, int BLOCK, int ITEMS>
 struct SweepSmem {
   static constexpr int WAVES = BLOCK / kWave;
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   for (int i = 0; i < ITEMS; ++i) {
     unsigned pos = s.whist[wave][dig[i]] + rank[i];
     rank[i] = static_cast<unsigned short>(pos);
-    if (full || (seg + i * kWave) < tile_count) stage_k[pos] = key[i];
+    if (full || (seg + i * kWave) < tile_count) stage_k[stage_swizzle(pos)] = key[i];
   }
   RS_STAMP(5);
 
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   for (int i = 0; i < ITEMS; ++i) {
     unsigned j = i * BLOCK + tid;
     if (full || j < tile_count) {
-      K k = stage_k[j];
+      K k = stage_k[stage_swizzle(j)];
       D o = s.gofs[digit_at(k, a.shift, a.bits)] + j;
 #ifdef RS_CHECKED
       if (static_cast<uint64_t>(o) >= a.n) { __hip_atomic_store(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
@@ -671,12 +678,12 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     V* stage_v = reinterpret_cast<V*>(s.stage);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-      if (full || (seg + i * kWave) < tile_count) stage_v[rank[i]] = val[i];
+      if (full || (seg + i * kWave) < tile_count) stage_v[stage_swizzle(rank[i])] = val[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       unsigned j = i * BLOCK + tid;
-      if (full || j < tile_count) vout[dst[i]] = stage_v[j];
+      if (full || j < tile_count) vout[dst[i]] = stage_v[stage_swizzle(j)];
     }
   }
 }
