@@ -85,7 +85,7 @@ namespace {
 constexpr size_t kCtrlHist = 0;
 constexpr size_t kCtrlBase = kMaxPasses * 256 * 8;
 constexpr size_t kCtrlTicket = 2 * kCtrlBase;
-constexpr size_t kCtrlError = kCtrlTicket + 64;
+constexpr size_t kCtrlError = kCtrlTicket + kMaxPasses * rsk::kTicketWords * sizeof(unsigned);   // per pass: one ticket word per XCD, a cache line apart
 constexpr size_t kCtrlBytes = kCtrlError + 64;   // error word at +0, order-check flags at +32
 
 int fail(rs_ctx* c, int code, const std::string& msg) {
@@ -366,7 +366,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     if (!live[p]) continue;
     rsk::SweepArgs a{};
     a.keys_in = kin; a.keys_out = kout; a.vals_in = vin; a.vals_out = vout;
-    a.desc = c->desc.p; a.ticket = tickets + p; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
+    a.desc = c->desc.p; a.ticket = tickets + p * rsk::kTicketWords; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
     a.n = n;
     a.fmask_in = done == 0 ? fmask : 0; a.smask_in = done == 0 ? smask : 0;                    // first launched pass
     a.fmask_out = done == n_live - 1 ? fmask : 0; a.smask_out = done == n_live - 1 ? smask : 0;  // last launched pass

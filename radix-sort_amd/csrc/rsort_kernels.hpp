@@ -286,13 +286,50 @@ template <> struct Desc<uint64_t> {
 };
 constexpr unsigned kCodeAgg = 1;
 
+// Tile order.  MI355X has 8 XCDs with private L2s, and workgroups are dealt to them round-robin.  The runs two
+// consecutive tiles write for one digit are adjacent in memory and almost never end on a 128-byte line, so the line
+// at every run boundary is written half by one tile and half by the next.  If those two tiles run on different XCDs,
+// each L2 holds a partial line and both write it back separately; tools/scatter_roofline.hip measures what that
+// costs without any sorting work: 256 streams x 256-byte runs, runs shifted by 64 bytes: 3.99 TB/s; the same with
+// the tiles dealt to the XCDs in groups of 8 consecutive tiles: 4.83 TB/s (aligned runs: 5.17 TB/s).
+// Tiles are therefore drawn from one ticket counter PER XCD: the k-th ticket of XCD x is tile
+//     (k / kXcdGroup) * 8 * kXcdGroup + x * kXcdGroup + k % kXcdGroup,
+// i.e. every XCD takes groups of kXcdGroup consecutive tiles and the partial lines inside a group meet in one L2.
+// A workgroup whose own XCD has run out draws from the others' counters.  Each counter hands out its tiles in
+// increasing order and every tile that has been drawn is running, so the lowest unfinished tile is either running or
+// next on an XCD whose earlier tiles are all finished, i.e. one with free workgroup slots (forward progress of the
+// look-back; the wait is bounded by a wall-clock timeout in any case).
+constexpr unsigned kXcds = 8;
+#ifndef RS_XCD_GROUP
+#define RS_XCD_GROUP 8
+#endif
+constexpr unsigned kXcdGroup = RS_XCD_GROUP;
+constexpr unsigned kTicketWords = kXcds * 32;      // one counter per XCD, 128 bytes apart
+constexpr unsigned kNoTile = 0xFFFFFFFFu;
+
+__device__ __forceinline__ unsigned xcc_id() {
+  // s_getreg_b32 HW_REG_XCC_ID (id 20 on gfx94x/gfx950), field XCC_ID = bits [3:0]
+  return static_cast<unsigned>(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20)) & (kXcds - 1);
+}
+
+__device__ __forceinline__ unsigned draw_tile(unsigned* tickets, unsigned tiles) {
+  const unsigned home = xcc_id();
+  for (unsigned step = 0; step < kXcds; ++step) {
+    const unsigned x = (home + step) & (kXcds - 1);
+    const unsigned k = atomicAdd(&tickets[x * 32], 1u);
+    const unsigned long long t = static_cast<unsigned long long>(k / kXcdGroup) * (kXcds * kXcdGroup) + x * kXcdGroup + k % kXcdGroup;
+    if (t < tiles) return static_cast<unsigned>(t);      // a counter's tiles increase with k: the first miss means it is exhausted
+  }
+  return kNoTile;
+}
+
 struct SweepArgs {
   const void* keys_in;
   void* keys_out;
   const void* vals_in;
   void* vals_out;
   void* desc;                       // [tiles][256] words of D
-  unsigned* ticket;                 // one counter for this pass, zero at launch
+  unsigned* ticket;                 // kTicketWords counters for this pass (one per XCD), zero at launch
   const unsigned long long* gbase;  // [256] for this pass
   unsigned* error_flag;             // set non-zero on a look-back timeout
   uint64_t n;
@@ -410,11 +447,12 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #ifdef RS_STAMPS
   unsigned long long stamp_begin = wall_clock64();
 #endif
-  if (tid == 0) s.tile_id = atomicAdd(a.ticket, 1u);
+  if (tid == 0) s.tile_id = draw_tile(a.ticket, static_cast<unsigned>((a.n + TILE - 1) / TILE));
 #pragma unroll
   for (int i = 0; i < kRadix / 2 / kWave; ++i) reinterpret_cast<unsigned*>(s.whist[wave])[i * kWave + lane] = 0;
   __syncthreads();
 
+  if (s.tile_id == kNoTile) return;               // workgroup-uniform; cannot happen with one workgroup per tile
   const uint64_t tile = s.tile_id;
 #ifdef RS_STAMPS
   if (tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096) rs_stamp_buf[tile >> 6] = stamp_begin;

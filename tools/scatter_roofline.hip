@@ -10,8 +10,18 @@
 #include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-__global__ __launch_bounds__(1024) void scatter_kernel(const uint4* in, uint4* out, unsigned tiles, unsigned streams, unsigned run16 /* 16-byte units per run */) {
-  const unsigned t = blockIdx.x;
+// shift16: every run is moved by this many 16-byte units, so that runs no longer start on a 128-byte line and the
+//          line at each run boundary is shared by two tiles;
+// group:   tiles are dealt to the XCDs in groups of `group` consecutive tiles (workgroup b runs on XCD b % 8), so
+//          that the two tiles sharing a line mostly run on the same XCD and meet in one L2.
+__global__ __launch_bounds__(1024) void scatter_kernel(const uint4* in, uint4* out, unsigned tiles, unsigned streams, unsigned run16 /* 16-byte units per run */,
+                                                       unsigned shift16, unsigned group) {
+  unsigned t = blockIdx.x;
+  if (group > 1) {
+    const unsigned xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    t = (slot / group) * (8 * group) + xcd * group + slot % group;
+    if (t >= tiles) return;
+  }
   const unsigned tile16 = 65536 / 16;                       // 4096 uint4 per tile
   const uint4* src = in + static_cast<size_t>(t) * tile16;
   const size_t stream16 = static_cast<size_t>(tiles) * tile16 / streams;   // uint4 per stream
@@ -22,7 +32,7 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const uint4* in, uint4* o
     const uint4 v = src[j];
     const unsigned r = j / run16, o = j % run16;
     const unsigned s = r % streams, k = r / streams;       // stream and the run's index among this tile's runs of that stream
-    out[static_cast<size_t>(s) * stream16 + (static_cast<size_t>(t) * runs_per_stream + k) * run16 + o] = v;
+    out[static_cast<size_t>(s) * stream16 + (static_cast<size_t>(t) * runs_per_stream + k) * run16 + o + shift16] = v;
   }
 }
 
@@ -30,20 +40,21 @@ int main(int argc, char** argv) {
   const size_t bytes = argc > 1 ? strtoull(argv[1], 0, 10) << 20 : 4096ull << 20;
   const unsigned tiles = bytes / 65536;
   uint4 *in, *out;
-  CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, bytes));
+  CK(hipMalloc(&in, bytes)); CK(hipMalloc(&out, bytes + 4096));
   CK(hipMemset(in, 1, bytes)); CK(hipMemset(out, 0, bytes));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const unsigned cfg[][2] = {{1, 65536}, {16, 4096}, {64, 1024}, {128, 512}, {256, 256}, {512, 128}, {1024, 64}};
+  const unsigned cfg[][4] = {{1, 65536, 0, 1}, {16, 4096, 0, 1}, {64, 1024, 0, 1}, {128, 512, 0, 1}, {256, 256, 0, 1}, {512, 128, 0, 1}, {1024, 64, 0, 1},
+                             {256, 256, 1, 1}, {256, 256, 4, 1}, {256, 256, 4, 8}, {256, 256, 4, 32}, {256, 256, 0, 8}, {1, 65536, 4, 1}};
   for (auto& c : cfg) {
     std::vector<float> ms;
     for (int it = 0; it < 7; ++it) {
       CK(hipEventRecord(e0));
-      hipLaunchKernelGGL(scatter_kernel, dim3(tiles), dim3(1024), 0, 0, in, out, tiles, c[0], c[1] / 16);
+      hipLaunchKernelGGL(scatter_kernel, dim3(tiles), dim3(1024), 0, 0, in, out, tiles, c[0], c[1] / 16, c[2], c[3]);
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float m; CK(hipEventElapsedTime(&m, e0, e1)); if (it >= 2) ms.push_back(m);
     }
     std::sort(ms.begin(), ms.end());
-    printf("streams %4u run %6u B : %.3f ms  %.2f TB/s (read+write)\n", c[0], c[1], ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
+    printf("streams %4u run %6u B shift %3u B xcd-group %2u : %.3f ms  %.2f TB/s (read+write)\n", c[0], c[1], c[2] * 16, c[3], ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
   }
   return 0;
 }
