@@ -73,6 +73,7 @@ struct rs_ctx {
   // ctrl layout: [0, 16K) ghist  u64[8][256]; [16K, 32K) gbase u64[8][256];
   //              [32K, 32K+64) tickets u32[16]; [32K+64, 32K+128) error flag (+pad)
   bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
+  bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   hipEvent_t ev[kMaxPasses + 2] = {};
@@ -372,6 +373,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.fmask_out = done == n_live - 1 ? fmask : 0; a.smask_out = done == n_live - 1 ? smask : 0;  // last launched pass
     a.shift = begin_bit + p * rsk::kRadixBits;
     a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
+    a.per_xcd_order = c->per_xcd_order ? 1 : 0;
     a.incl_code = 2u + (done & 1);          // alternates over the LAUNCHED passes (descriptor parity, rsort_kernels.hpp)
     launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, s);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
@@ -442,6 +444,26 @@ int rs_ctx_create(rs_ctx** out, int device) {
       (void)hipFree(d_bad);
     }
     c->rank_by_lds_atomic = h_bad == 0;
+  }
+
+  // Tile order: one ticket counter per XCD needs workgroups on every XCD, under the XCC ids the kernel reads.
+  // Probed here: 1024 one-wave workgroups count themselves per id; the order is enabled only if all 8 ids appear with
+  // at least half their fair share.  RSORT_XCD=0 keeps the single counter (tests, A/B timing).
+  {
+    const char* env = std::getenv("RSORT_XCD");
+    unsigned* d_cnt = nullptr;
+    unsigned h_cnt[rsk::kXcds] = {};
+    if (!(env && env[0] == '0') && hipMalloc(&d_cnt, sizeof(h_cnt)) == hipSuccess) {
+      bool ok = hipMemsetAsync(d_cnt, 0, sizeof(h_cnt), c->stream) == hipSuccess;
+      if (ok) {
+        hipLaunchKernelGGL(rsk::xcc_probe_kernel, dim3(1024), dim3(64), 0, c->stream, d_cnt);
+        ok = hipMemcpyAsync(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+             hipStreamSynchronize(c->stream) == hipSuccess;
+      }
+      (void)hipFree(d_cnt);
+      for (unsigned x = 0; ok && x < rsk::kXcds; ++x) ok = h_cnt[x] >= 1024 / rsk::kXcds / 2;
+      c->per_xcd_order = ok;
+    }
   }
   *out = c;
   return RS_OK;

@@ -312,7 +312,18 @@ __device__ __forceinline__ unsigned xcc_id() {
   return static_cast<unsigned>(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20)) & (kXcds - 1);
 }
 
-__device__ __forceinline__ unsigned draw_tile(unsigned* tickets, unsigned tiles) {
+// Probe for the tile order: every workgroup counts itself under the XCC id it reads.  The host enables the per-XCD
+// order only if all kXcds ids show up with similar counts (a partitioned device or a different register layout would
+// put everything on one id, and the per-XCD order would then starve the look-back).
+__global__ __launch_bounds__(64) void xcc_probe_kernel(unsigned* counts) {
+  if (threadIdx.x == 0) atomicAdd(&counts[xcc_id()], 1u);
+}
+
+__device__ __forceinline__ unsigned draw_tile(unsigned* tickets, unsigned tiles, bool per_xcd) {
+  if (!per_xcd) {                                 // one counter: tile = ticket
+    const unsigned k = atomicAdd(&tickets[0], 1u);
+    return k < tiles ? k : kNoTile;
+  }
   const unsigned home = xcc_id();
   for (unsigned step = 0; step < kXcds; ++step) {
     const unsigned x = (home + step) & (kXcds - 1);
@@ -338,6 +349,7 @@ struct SweepArgs {
   int shift;
   int bits;
   unsigned incl_code;               // 2 + (pass & 1)
+  int per_xcd_order;                // tiles from one ticket counter per XCD (rs_ctx_create probes whether that is safe)
 };
 
 // Lanes of the wave whose digit DIFFERS from this lane's, as two 32-bit halves: per bit, the
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #ifdef RS_STAMPS
   unsigned long long stamp_begin = wall_clock64();
 #endif
-  if (tid == 0) s.tile_id = draw_tile(a.ticket, static_cast<unsigned>((a.n + TILE - 1) / TILE));
+  if (tid == 0) s.tile_id = draw_tile(a.ticket, static_cast<unsigned>((a.n + TILE - 1) / TILE), a.per_xcd_order != 0);
 #pragma unroll
   for (int i = 0; i < kRadix / 2 / kWave; ++i) reinterpret_cast<unsigned*>(s.whist[wave])[i * kWave + lane] = 0;
   __syncthreads();

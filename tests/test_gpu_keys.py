@@ -57,9 +57,12 @@ def test_precheck_paths(engine, oracle):
     assert engine.sort_keys_host(v, 1).tobytes() == np.sort(v).tobytes()
 
 
-def test_wide_descriptor_path(oracle):
-    """n > 2^30 switches the look-back descriptors and output offsets to 8 bytes; RSORT_FORCE_WIDE=1 takes that
-    path at test sizes (a child process, because the switch is read once per process)."""
+@pytest.mark.parametrize("switch", ["RSORT_FORCE_WIDE=1", "RSORT_XCD=0", "RSORT_RANK=ballot"])
+def test_alternate_paths(oracle, switch):
+    """Paths the product takes only in special situations, forced at test sizes (a child process each, because the
+    switches are read once per process): RSORT_FORCE_WIDE=1 -- 8-byte look-back descriptors and offsets (n > 2^30);
+    RSORT_XCD=0 -- one ticket counter instead of one per XCD (what a failed XCC-id probe selects);
+    RSORT_RANK=ballot -- ballot/bitop3 ranking (what a failed LDS lane-order probe selects)."""
     import os
     import subprocess
     import sys
@@ -84,7 +87,8 @@ assert gk.tobytes() == wk.tobytes() and (gp == wp).all()
 print("WIDE OK")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, RSORT_FORCE_WIDE="1")
+    name, value = switch.split("=")
+    env = dict(os.environ, **{name: value})
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "WIDE OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
