@@ -728,12 +728,12 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     V* stage_v = reinterpret_cast<V*>(s.stage);
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
-      if (full || (seg + i * kWave) < tile_count) stage_v[stage_swizzle(rank[i])] = val[i];
+      if (full || (seg + i * kWave) < tile_count) stage_v[rank[i]] = val[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       unsigned j = i * BLOCK + tid;
-      if (full || j < tile_count) vout[dst[i]] = stage_v[stage_swizzle(j)];
+      if (full || j < tile_count) vout[dst[i]] = stage_v[j];
     }
   }
 }
