@@ -36,6 +36,32 @@ __global__ __launch_bounds__(1024) void scatter_kernel(const uint4* in, uint4* o
   }
 }
 
+// The same pattern with 4-byte loads and stores per lane (what a sort kernel that moves single keys issues): thread t moves
+// dwords t, t + 1024, ... of the tile, 16 per thread.
+__global__ __launch_bounds__(1024) void scatter_kernel_dword(const unsigned* in, unsigned* out, unsigned tiles, unsigned streams, unsigned run4,
+                                                             unsigned shift4, unsigned group) {
+  unsigned t = blockIdx.x;
+  if (group > 1) {
+    const unsigned xcd = blockIdx.x % 8, slot = blockIdx.x / 8;
+    t = (slot / group) * (8 * group) + xcd * group + slot % group;
+    if (t >= tiles) return;
+  }
+  const unsigned tile4 = 65536 / 4;
+  const unsigned* src = in + static_cast<size_t>(t) * tile4;
+  const size_t stream4 = static_cast<size_t>(tiles) * tile4 / streams;
+  const unsigned runs_per_stream = tile4 / run4 / streams;
+  unsigned v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = src[i * 1024 + threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const unsigned j = i * 1024 + threadIdx.x;
+    const unsigned r = j / run4, o = j % run4;
+    const unsigned s = r % streams, k = r / streams;
+    out[static_cast<size_t>(s) * stream4 + (static_cast<size_t>(t) * runs_per_stream + k) * run4 + o + shift4] = v[i];
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = argc > 1 ? strtoull(argv[1], 0, 10) << 20 : 4096ull << 20;
   const unsigned tiles = bytes / 65536;
@@ -55,6 +81,18 @@ int main(int argc, char** argv) {
     }
     std::sort(ms.begin(), ms.end());
     printf("streams %4u run %6u B shift %3u B xcd-group %2u : %.3f ms  %.2f TB/s (read+write)\n", c[0], c[1], c[2] * 16, c[3], ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
+  }
+  const unsigned cfg4[][4] = {{1, 65536, 0, 1}, {256, 256, 0, 1}, {256, 256, 64, 1}, {256, 256, 64, 8}, {256, 256, 20, 8}, {256, 256, 0, 8}};
+  for (auto& c : cfg4) {
+    std::vector<float> ms;
+    for (int it = 0; it < 7; ++it) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(scatter_kernel_dword, dim3(tiles), dim3(1024), 0, 0, reinterpret_cast<const unsigned*>(in), reinterpret_cast<unsigned*>(out), tiles, c[0], c[1] / 4, c[2] / 4, c[3]);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float m; CK(hipEventElapsedTime(&m, e0, e1)); if (it >= 2) ms.push_back(m);
+    }
+    std::sort(ms.begin(), ms.end());
+    printf("4-byte lanes: streams %4u run %6u B shift %3u B xcd-group %2u : %.3f ms  %.2f TB/s (read+write)\n", c[0], c[1], c[2], c[3], ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
   }
   return 0;
 }
