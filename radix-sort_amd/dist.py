@@ -126,11 +126,14 @@ class Comm:
 
     def all_to_all(self, send, send_counts, recv_counts, recv):
         """Variable all-to-all of a 1-D tensor; with gloo the payload is staged through host memory.
-        Elements travel as bytes: neither RCCL nor gloo takes every key width (16-bit integers)."""
+        Element types the backends do not take (16-bit integers) travel as bytes."""
         import torch
-        es = send.element_size()
-        ins, outs = [int(x) * es for x in send_counts], [int(x) * es for x in recv_counts]
-        sb, rb = send.view(torch.uint8), recv.view(torch.uint8)
+        ins, outs = [int(x) for x in send_counts], [int(x) for x in recv_counts]
+        sb, rb = send, recv
+        if send.dtype not in (torch.int8, torch.uint8, torch.int32, torch.int64):
+            es = send.element_size()
+            ins, outs = [x * es for x in ins], [x * es for x in outs]
+            sb, rb = send.view(torch.uint8), recv.view(torch.uint8)
         if self.backend == "nccl" or not send.is_cuda:
             self.dist.all_to_all_single(rb, sb, output_split_sizes=outs, input_split_sizes=ins, group=self.group)
         else:
