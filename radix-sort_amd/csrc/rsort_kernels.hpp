@@ -117,25 +117,63 @@ template <typename K> __device__ __forceinline__ K order_field(K k, const OrderA
 
 template <typename K, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void order_check_kernel(OrderArgs a) {
-  constexpr int ITEMS = 8;
+  constexpr int VEC = 16 / sizeof(K);          // 16 bytes per lane per load
+  constexpr int UNROLL = 4;                    // packs in flight per lane
+  constexpr int CHECK_EVERY = 8;               // iterations between two looks at the flags (a coherent load each)
   const K* keys = static_cast<const K*>(a.keys);
-  const uint64_t chunk = static_cast<uint64_t>(BLOCK) * ITEMS;
-  for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * chunk; base + 1 < a.n; base += static_cast<uint64_t>(gridDim.x) * chunk) {
-    const unsigned seen = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (seen == 3u) return;
-    unsigned f = 0;
-#pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
-      uint64_t j = base + static_cast<uint64_t>(i) * BLOCK + threadIdx.x;
-      if (j + 1 < a.n) {
-        K x = order_field(keys[j], a), y = order_field(keys[j + 1], a);
-        f |= (x > y ? 1u : 0u) | (x < y ? 2u : 0u);
-      }
-    }
-    // set a bit only if this chunk did not already see it set: one word must not take an atomic per wave and chunk
+  // neighbour pairs (j, j+1), j < n-1.  Packs of VEC keys start at the first 16-byte boundary; a lane checks the pairs
+  // inside its pack and the pair that leaves it (one extra key: the first of the next pack, same cache line or the next).
+  uint64_t head = ((16u - (reinterpret_cast<uintptr_t>(keys) & 15u)) & 15u) / sizeof(K);
+  if (head > a.n) head = a.n;
+  const uint64_t npack = (a.n - head) / VEC;
+  struct alignas(16) Pack { K v[VEC]; };
+  const Pack* packs = reinterpret_cast<const Pack*>(keys + head);
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * BLOCK;
+  unsigned seen = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (seen == 3u) return;                      // unordered input: the one-workgroup probe launch has already said so
+  unsigned f = 0;
+  auto pair = [&](K x, K y) { f |= (x > y ? 1u : 0u) | (x < y ? 2u : 0u); };
+  auto flush = [&]() {
+    // set a bit only if it was not seen set: the one flag word must not take an atomic per wave and iteration
     if (!(seen & 1u) && __ballot(f & 1u) && (threadIdx.x & 63) == 0) atomicOr(a.flags, 1u);
     if (!(seen & 2u) && __ballot(f & 2u) && (threadIdx.x & 63) == 0) atomicOr(a.flags, 2u);
+  };
+  if (blockIdx.x == 0) {                        // head and tail pairs, one per thread (fewer than 3 * VEC of them)
+    const uint64_t tail0 = head + npack * VEC;  // first key after the packs
+    uint64_t j = threadIdx.x;
+    if (j < head && j + 1 < a.n) pair(order_field(keys[j], a), order_field(keys[j + 1], a));
+    j = (tail0 > 0 ? tail0 - 1 : 0) + threadIdx.x;            // the pair leaving the last pack, then the tail
+    if (j + 1 < a.n && j >= head) pair(order_field(keys[j], a), order_field(keys[j + 1], a));
   }
+  int since = 0;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x; i < npack; i += UNROLL * stride) {
+    if (++since == CHECK_EVERY) {
+      since = 0;
+      flush();
+      seen = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen == 3u) return;
+    }
+    Pack pk[UNROLL];
+    K nxt[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint64_t p = i + u * stride;
+      if (p < npack) {
+        pk[u] = packs[p];
+        nxt[u] = p + 1 < npack ? packs[p + 1].v[0] : pk[u].v[VEC - 1];   // the last pack's outgoing pair belongs to block 0
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      if (i + u * stride < npack) {
+        K prev = order_field(pk[u].v[0], a);
+#pragma unroll
+        for (int e = 1; e < VEC; ++e) { K cur = order_field(pk[u].v[e], a); pair(prev, cur); prev = cur; }
+        pair(prev, order_field(nxt[u], a));
+      }
+    }
+  }
+  flush();
 }
 
 // in-place reversal (std::reverse, radix_sort.hpp:300)
