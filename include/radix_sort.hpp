@@ -16,12 +16,14 @@
 //   key path, numeric key   (:1543-1592)  -> key column + index payload, rs_sort_pairs (stable),
 //                                            then the moves of sortByIndices (:1111-1133)
 //   key path, string key    (:1574-1578)  -> pack projected strings, rs_sort_strings (stable), moves
-// The third argument is accepted for source compatibility; the device path is always parallel.
+// The third argument keeps its meaning for the steps that stay on the host (key column, string packing, moving the
+// objects: threaded by the reference's own rule when it is true); the device path is always parallel.
 // The reference's pre-checks (already sorted -> return, :269-305 / :746-769) and insertion-sort
 // thresholds (:42-43) change its running time, never its result, and are not reproduced.
 //
 // Link with:  -L<repo>/radix-sort_amd/lib -lrsort_hip
 #pragma once
+#include <algorithm>
 #include <concepts>
 #include <cstddef>
 #include <cstdint>
@@ -31,6 +33,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -104,10 +107,56 @@ namespace radix_sort
 						"ERROR: generators.hpp requires IEEE-754/IEC-559 compliance.\n");   // :701-707
 			}
 
-			// tmp[i] = move(v[perm[i]]), then swap: the single-threaded body of sortByIndices (:1126-1132)
-			template <typename T, typename I>
-			inline void applyPermutation(std::vector<T>& v, const std::vector<I>& perm)
+			// Host threads for the steps that stay on the CPU (key column, string packing, moving the objects): the
+			// reference's rule (getNumOfThreads :112-123) -- one thread below 2,000,000 elements, else the largest power
+			// of two <= n / 1,000,000, capped by the hardware threads and by 12 -- and only when the caller asked for
+			// multi-threading, as sortByIndices does (:1121-1153).
+			inline std::size_t hostThreads(std::size_t n, bool enableMultiThreading)
 			{
+				if (!enableMultiThreading || n < 2'000'000)
+					return 1;
+				std::size_t t = 1;
+				while ((t << 1) <= n / 1'000'000)
+					t <<= 1;
+				const std::size_t hw = std::max<std::size_t>(1, std::thread::hardware_concurrency());
+				return std::min({ t, hw, std::size_t(12) });
+			}
+
+			// body(lo, hi) over [0, n) cut into `threads` contiguous ranges (the last one takes the remainder)
+			template <typename Body>
+			inline void forRanges(std::size_t n, std::size_t threads, Body&& body)
+			{
+				if (threads <= 1)
+				{
+					body(std::size_t(0), n, std::size_t(0));
+					return;
+				}
+				std::vector<std::thread> pool;
+				pool.reserve(threads);
+				const std::size_t step = n / threads;
+				for (std::size_t t = 0; t < threads; t++)
+					pool.emplace_back([&body, t, step, n, threads] { body(t * step, t + 1 == threads ? n : (t + 1) * step, t); });
+				for (auto& th : pool)
+					th.join();
+			}
+
+			// tmp[i] = move(v[perm[i]]), then swap: sortByIndices (:1111-1154), threaded like it when asked to
+			template <typename T, typename I>
+			inline void applyPermutation(std::vector<T>& v, const std::vector<I>& perm, std::size_t threads)
+			{
+				if constexpr (std::default_initializable<T>)
+				{
+					if (threads > 1)
+					{
+						std::vector<T> tmp(v.size());
+						forRanges(v.size(), threads, [&](std::size_t lo, std::size_t hi, std::size_t) {
+							for (std::size_t i = lo; i < hi; i++)
+								tmp[i] = std::move(v[static_cast<std::size_t>(perm[i])]);
+						});
+						std::swap(tmp, v);
+						return;
+					}
+				}
 				std::vector<T> tmp;
 				tmp.reserve(v.size());
 				for (const auto& i : perm)
@@ -122,41 +171,52 @@ namespace radix_sort
 			};
 
 			template <typename T, typename Proj>
-			inline PackedStrings packStrings(const std::vector<T>& v, Proj& proj)
+			inline PackedStrings packStrings(const std::vector<T>& v, Proj& proj, std::size_t threads)
 			{
 				PackedStrings p;
-				p.offsets.resize(v.size() + 1);
-				std::uint64_t total = 0;
-				for (std::size_t i = 0; i < v.size(); i++)
-				{
-					p.offsets[i] = total;
-					total += std::invoke(proj, v[i]).size();
-				}
-				p.offsets[v.size()] = total;
-				p.blob.resize(total);
-				for (std::size_t i = 0; i < v.size(); i++)
-				{
-					const std::string& s = std::invoke(proj, v[i]);
-					std::copy(s.begin(), s.end(), p.blob.begin() + static_cast<std::ptrdiff_t>(p.offsets[i]));
-				}
+				const std::size_t n = v.size();
+				p.offsets.resize(n + 1);
+				// lengths per range, then the ranges' starting offsets, then offsets and bytes
+				std::vector<std::uint64_t> rangeBytes(std::max<std::size_t>(threads, 1) + 1, 0);
+				forRanges(n, threads, [&](std::size_t lo, std::size_t hi, std::size_t t) {
+					std::uint64_t total = 0;
+					for (std::size_t i = lo; i < hi; i++)
+						total += std::invoke(proj, v[i]).size();
+					rangeBytes[t + 1] = total;
+				});
+				for (std::size_t t = 1; t < rangeBytes.size(); t++)
+					rangeBytes[t] += rangeBytes[t - 1];
+				p.offsets[n] = rangeBytes.back();
+				p.blob.resize(rangeBytes.back());
+				forRanges(n, threads, [&](std::size_t lo, std::size_t hi, std::size_t t) {
+					std::uint64_t at = rangeBytes[t];
+					for (std::size_t i = lo; i < hi; i++)
+					{
+						const std::string& s = std::invoke(proj, v[i]);
+						p.offsets[i] = at;
+						std::copy(s.begin(), s.end(), p.blob.begin() + static_cast<std::ptrdiff_t>(at));
+						at += s.size();
+					}
+				});
 				return p;
 			}
 
 			template <typename T, typename Proj>
-			inline void sortByStringKey(std::vector<T>& v, Proj& proj, bool stable)
+			inline void sortByStringKey(std::vector<T>& v, Proj& proj, bool stable, bool enableMultiThreading)
 			{
-				PackedStrings p = packStrings(v, proj);
+				const std::size_t threads = hostThreads(v.size(), enableMultiThreading);
+				PackedStrings p = packStrings(v, proj, threads);
 				std::vector<std::uint64_t> perm(v.size());
 				rs_ctx* ctx = context();
 				check(ctx, rs_sort_strings(ctx, p.blob.data(), p.offsets.data(), v.size(), perm.data(), stable ? 1 : 0));
-				applyPermutation(v, perm);
+				applyPermutation(v, perm, threads);
 			}
 		}
 
 		namespace value
 		{
 			template <shared::supported T>
-			inline void sortDispatcher(std::vector<T>& v, bool /*enableMultiThreading*/)
+			inline void sortDispatcher(std::vector<T>& v, bool enableMultiThreading)
 			{
 				if (v.size() < 2)
 					return;
@@ -164,7 +224,7 @@ namespace radix_sort
 				if constexpr (shared::is_string<T>)
 				{
 					std::identity id;
-					device::sortByStringKey(v, id, false);
+					device::sortByStringKey(v, id, false, enableMultiThreading);
 				}
 				else
 				{
@@ -182,7 +242,7 @@ namespace radix_sort
 		{
 			template <typename T, typename Proj>
 			requires shared::sortable<T, Proj>
-			inline void sortDispatcher(std::vector<T>& v, Proj proj, bool /*enableMultiThreading*/)
+			inline void sortDispatcher(std::vector<T>& v, Proj proj, bool enableMultiThreading)
 			{
 				using Key = shared::sort_key<T, Proj>;
 				const std::size_t SIZE = v.size();
@@ -191,16 +251,18 @@ namespace radix_sort
 
 				if constexpr (shared::is_string<Key>)
 				{
-					device::sortByStringKey(v, proj, true);
+					device::sortByStringKey(v, proj, true, enableMultiThreading);
 				}
 				else
 				{
 					device::checkKeyType<Key>();
 
-					std::vector<Key> k;                       // the key column (:1581-1585)
-					k.reserve(SIZE);
-					for (const auto& obj : v)
-						k.emplace_back(std::invoke(proj, obj));
+					const std::size_t threads = device::hostThreads(SIZE, enableMultiThreading);
+					std::vector<Key> k(SIZE);                 // the key column (:1581-1585)
+					device::forRanges(SIZE, threads, [&](std::size_t lo, std::size_t hi, std::size_t) {
+						for (std::size_t i = lo; i < hi; i++)
+							k[i] = std::invoke(proj, v[i]);
+					});
 
 					rs_ctx* ctx = device::context();
 					constexpr int XF = device::transformOf<Key>();
@@ -212,7 +274,7 @@ namespace radix_sort
 						for (std::size_t i = 0; i < SIZE; i++)
 							indices[i] = static_cast<std::uint32_t>(i);
 						device::check(ctx, rs_sort_pairs(ctx, k.data(), indices.data(), SIZE, static_cast<int>(sizeof(Key)), 4, XF, 0, BITS));
-						device::applyPermutation(v, indices);
+						device::applyPermutation(v, indices, threads);
 					}
 					else
 					{
@@ -220,7 +282,7 @@ namespace radix_sort
 						for (std::size_t i = 0; i < SIZE; i++)
 							indices[i] = i;
 						device::check(ctx, rs_sort_pairs(ctx, k.data(), indices.data(), SIZE, static_cast<int>(sizeof(Key)), 8, XF, 0, BITS));
-						device::applyPermutation(v, indices);
+						device::applyPermutation(v, indices, threads);
 					}
 				}
 			}

@@ -105,6 +105,12 @@ int main() {
         check_key<std::string>("complex_str", n, shape);
       }
     }
+  // above 2,000,000 elements with the third argument true the host-side steps (key column, string packing, moving
+  // the objects) run on several threads, by the reference's own rule (getNumOfThreads, radix_sort.hpp:112-123)
+  check_key<int>("complex_i32_threaded", 2100001, 0);
+  check_key<double>("complex_double_threaded", 2100001, 1);     // shape 1 calls sort(v, proj) without the flag: serial host path
+  check_key<std::string>("complex_str_threaded", 2100001, 0);
+  check_value<std::string>("string_threaded", 2100001, 0);
   std::printf("%d cases, WRONG SORTS: %d\n", cases, failures);
   return failures ? 1 : 0;
 }
