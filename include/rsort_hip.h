@@ -99,6 +99,17 @@ int rs_sort_pairs_device(rs_ctx* ctx, void* d_keys, void* d_values, void* d_alt_
 int rs_digit_histogram_device(rs_ctx* ctx, const void* d_keys, size_t n, int key_bytes, int transform,
                               int begin_bit, int end_bit, uint64_t* h_counts);
 
+/* rs_partition_device: ONE stable pass, out of place: d_keys_out = d_keys_in reordered by the digit at
+ *   [begin_bit, end_bit) (at most 8 bits) of the transformed key, raw key bits unchanged; values (value_bytes 4 or 8, or
+ *   0 with null pointers) move with their keys; h_counts[256] (optional) receives the digit counts.  Synchronises
+ *   (the counts come back before the pass is launched); the pass itself is only queued.
+ *   Result == one iteration of the LSD loop (count :125-153, prefix :193-208, scatter :447-470 / :1062-1109) = the
+ *   bucket layout partitionRegions (:210-254) produces for one MSD level.  The multi-GPU splitter uses it to make every
+ *   destination's keys contiguous without the copy back that an in-place call needs after an odd number of passes. */
+int rs_partition_device(rs_ctx* ctx, const void* d_keys_in, void* d_keys_out, const void* d_values_in,
+                        void* d_values_out, size_t n, int key_bytes, int value_bytes, int transform,
+                        int begin_bit, int end_bit, uint64_t* h_counts);
+
 /* ---- host-buffer entry points (what include/radix_sort.hpp calls) --------------------------------
  * Same contracts; buffers are host memory; H2D, sort, D2H run on the context's stream and the call
  * returns after the data is back. */

@@ -550,6 +550,67 @@ int rs_sort_pairs_device(rs_ctx* c, void* d_keys, void* d_values, void* d_alt_ke
                      begin_bit, end_bit);
 }
 
+int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, const void* d_values_in, void* d_values_out,
+                        size_t n, int key_bytes, int value_bytes, int transform, int begin_bit, int end_bit,
+                        uint64_t* h_counts) {
+  int rc = check_args(c, d_keys_in, n, key_bytes, value_bytes, transform, begin_bit, end_bit);
+  if (rc != RS_OK) return rc;
+  if (end_bit - begin_bit > rsk::kRadixBits) return fail(c, RS_ERR_ARG, "rs_partition_device moves keys by one digit: end_bit - begin_bit <= 8");
+  if (n > 0 && !d_keys_out) return fail(c, RS_ERR_ARG, "null output pointer");
+  if (value_bytes && n > 0 && (!d_values_in || !d_values_out)) return fail(c, RS_ERR_ARG, "null value pointer");
+  if (h_counts) std::memset(h_counts, 0, sizeof(uint64_t) * 256);
+  if (n == 0) return RS_OK;
+  RS_HIP(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t tiles = tiles_for(n, key_bytes, value_bytes);
+  static const bool force_wide = [] { const char* e = std::getenv("RSORT_FORCE_WIDE"); return e && e[0] == '1'; }();
+  const bool wide = n > kSmallDescLimit || force_wide;
+  if (tiles > 0x7FFFFFFFull) return fail(c, RS_ERR_ARG, "n too large for one launch");
+  if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
+  if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
+  char* ctrl = static_cast<char*>(c->ctrl.p);
+  auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);
+  auto* gbase = reinterpret_cast<unsigned long long*>(ctrl + kCtrlBase);
+  auto* tickets = reinterpret_cast<unsigned*>(ctrl + kCtrlTicket);
+  auto* error_flag = reinterpret_cast<unsigned*>(ctrl + kCtrlError);
+  const uint64_t sign = 1ull << (key_bytes * 8 - 1);
+  const uint64_t all = key_bytes == 8 ? ~0ull : ((1ull << (key_bytes * 8)) - 1ull);
+  const uint64_t fmask = transform == RS_XF_IEEE ? all : 0;
+  const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
+
+  RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlBytes, s));
+  RS_HIP(c, hipMemsetAsync(c->desc.p, 0, tiles * 256 * (wide ? 8 : 4), s));
+  rsk::HistArgs h{};
+  h.keys = d_keys_in; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
+  h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = 1;
+  launch_hist(h, key_bytes, hist_grid(n, key_bytes), s);
+  hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(1), dim3(rsk::kRadix), 0, s, ghist, gbase);
+  unsigned long long counts[256];
+  RS_HIP(c, hipMemcpyAsync(counts, ghist, sizeof(counts), hipMemcpyDeviceToHost, s));
+  RS_HIP(c, hipStreamSynchronize(s));
+  bool constant = false;
+  for (int d = 0; d < 256; ++d) {
+    if (h_counts) h_counts[d] = counts[d];
+    constant = constant || counts[d] == n;
+  }
+  if (constant) {            // one digit for all keys: the partition is the identity
+    RS_HIP(c, hipMemcpyAsync(d_keys_out, d_keys_in, n * key_bytes, hipMemcpyDeviceToDevice, s));
+    if (value_bytes) RS_HIP(c, hipMemcpyAsync(d_values_out, d_values_in, n * value_bytes, hipMemcpyDeviceToDevice, s));
+    return RS_OK;
+  }
+  rsk::SweepArgs a{};
+  a.keys_in = d_keys_in; a.keys_out = d_keys_out; a.vals_in = d_values_in; a.vals_out = d_values_out;
+  a.desc = c->desc.p; a.ticket = tickets; a.gbase = gbase; a.error_flag = error_flag;
+  a.n = n;
+  a.fmask_in = fmask; a.smask_in = smask; a.fmask_out = fmask; a.smask_out = smask;   // ordered on the transformed digit, stored as they came
+  a.shift = begin_bit; a.bits = end_bit - begin_bit;
+  a.per_xcd_order = c->per_xcd_order ? 1 : 0;
+  a.incl_code = 2u;
+  launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, s);
+  RS_HIP(c, hipGetLastError());
+  return RS_OK;
+}
+
 int rs_sort_keys(rs_ctx* c, void* h_keys, size_t n, int key_bytes, int transform, int begin_bit, int end_bit) {
   int rc = check_args(c, h_keys, n, key_bytes, 0, transform, begin_bit, end_bit);
   if (rc != RS_OK) return rc;

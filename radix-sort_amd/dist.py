@@ -177,6 +177,16 @@ class HipLocal:
                                     scratch.data_ptr() if scratch is not None else None,
                                     vscratch.data_ptr() if vscratch is not None else None, begin_bit, end_bit)
 
+    def partition_out(self, t, out, begin_bit, end_bit, vals=None, vout=None):
+        """out = t stably reordered by the digit at [begin_bit, end_bit) (vout = vals likewise); returns the digit counts."""
+        n = t.numel()
+        if vals is None:
+            h = self.eng.partition_ptr(t.data_ptr(), out.data_ptr(), n, self.kb, self.xf, begin_bit, end_bit)
+        else:
+            h = self.eng.partition_ptr(t.data_ptr(), out.data_ptr(), n, self.kb, self.xf, begin_bit, end_bit,
+                                       vals.data_ptr(), vout.data_ptr(), vals.element_size())
+        return h.astype(np.int64)
+
     def sort(self, t, scratch=None, vals=None, vscratch=None):
         n = t.numel()
         if n <= 1:
@@ -197,7 +207,7 @@ class HipLocal:
 # ---------------------------------------------------------------------------------------------
 def distributed_sort(keys, local, comm: Comm, values=None):
     """keys: this rank's 1-D tensor of raw key bits (int32 / int64 ...).  Returns this rank's slice of
-    the globally sorted sequence (a new tensor); `keys` is used as scratch and is clobbered.
+    the globally sorted sequence (a new tensor); `keys` (and `values`) are used as scratch and are clobbered.
 
     values: optional 1-D payload tensor (4- or 8-byte elements) that travels with the keys; the result is then
     (keys, values) and the sort is STABLE over the concatenation of the ranks' inputs in rank order -- equal keys keep
@@ -214,12 +224,15 @@ def distributed_sort(keys, local, comm: Comm, values=None):
     scratch = local.empty_like(keys, n)
     vscratch = local.empty_like(values, n) if values is not None else None
 
-    # 1-2. top-digit histogram, all-gathered
-    h1 = local.histogram(keys, 0, n, top - DIGIT, top)
-    level1_all = comm.all_gather_table(h1, keys.device)                    # [G, 256]
+    # 1 + 4a. local MSD partition on the top digit, out of place (independent of the other ranks' counts); the pass
+    # hands back the digit counts it needed anyway, and the two buffers swap roles instead of copying back
+    h1 = local.partition_out(keys, scratch, top - DIGIT, top, values, vscratch)
+    keys, scratch = scratch, keys
+    if values is not None:
+        values, vscratch = vscratch, values
 
-    # 4a. local MSD partition on the top digit (independent of the other ranks' counts)
-    local.partition(keys, 0, n, top - DIGIT, top, scratch, values, vscratch)
+    # 2. the counts, all-gathered
+    level1_all = comm.all_gather_table(h1, keys.device)                    # [G, 256]
 
     # 3. refine the buckets that hold a quantile; 4b. partition those buckets on the second digit
     refine = boundary_buckets(level1_all, world) if top >= 2 * DIGIT else []

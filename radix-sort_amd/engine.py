@@ -81,6 +81,15 @@ class Engine:
                                                     end_bit, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def partition_ptr(self, d_keys_in, d_keys_out, n, key_bytes, transform, begin_bit, end_bit, d_vals_in=None,
+                      d_vals_out=None, value_bytes=0):
+        """One stable out-of-place pass on the digit [begin_bit, end_bit) (<= 8 bits); returns its 256 digit counts."""
+        counts = np.zeros(256, dtype=np.uint64)
+        self._ck(self.lib.rs_partition_device(self.h, C.c_void_p(d_keys_in or None), C.c_void_p(d_keys_out or None),
+                                              C.c_void_p(d_vals_in or None), C.c_void_p(d_vals_out or None), n, key_bytes,
+                                              value_bytes, transform, begin_bit, end_bit, counts.ctypes.data_as(C.c_void_p)))
+        return counts
+
     # ---- torch tensors on the engine's device ------------------------------------------------------
     def sort_keys_(self, t, transform, alt=None, begin_bit=0, end_bit=None):
         """In-place sort of a contiguous 1-D device tensor whose element size is the key width."""

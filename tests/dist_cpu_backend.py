@@ -40,6 +40,15 @@ class NumpyLocal:
             v = vals.numpy()
             v[lo:hi] = v[lo:hi][order]
 
+    def partition_out(self, t, out, begin_bit, end_bit, vals=None, vout=None):
+        a = t.numpy()
+        d = self._digit(a, begin_bit, end_bit)
+        order = np.argsort(d, kind="stable")
+        out.numpy()[:] = a[order]
+        if vals is not None:
+            vout.numpy()[:] = vals.numpy()[order]
+        return np.bincount(d, minlength=256).astype(np.int64)
+
     def _typed(self, a):
         return a.view({4: np.float32, 8: np.float64}[self.kb]) if self.xf == 2 else a.view(_U[self.kb])
 
