@@ -66,6 +66,16 @@ int rs_ctx_synchronize(rs_ctx* ctx);
  * engine with the check both on and off. */
 int rs_ctx_set_precheck(rs_ctx* ctx, int enabled);
 
+/* Tile order of the sort pass (default: per XCD when the device probe at rs_ctx_create allows it).  MI355X deals
+ * workgroups to 8 XCDs with private L2s; handing each XCD groups of 8 consecutive tiles lets the partial cache lines at
+ * the boundaries of the runs that consecutive tiles write meet in one L2 (7 % per pass at N = 2^30).  With that order a
+ * tile may wait for a tile whose workgroup is not launched yet; a sort running alone always gets it launched, and sorts
+ * of fewer than 1024 tiles use the single-counter order anyway.  Callers that run several LARGE sorts on one device at
+ * the same time (several contexts or processes) should pass 0: waiting workgroups of one sort could otherwise hold
+ * the slots another sort needs (the wait is bounded: such a sort would fail with RS_ERR_KERNEL after 2 s, not hang).
+ * No counterpart in the reference (a CPU library). */
+int rs_ctx_set_tile_order(rs_ctx* ctx, int per_xcd);
+
 /* Per-kernel timing with HIP events on the context's stream (for bench.py's roofline block).
  * After a sort with profiling on, rs_ctx_get_profile fills ms[0] = histogram+scan,
  * ms[1..passes] = the onesweep passes in order; *count = 1 + passes.  Synchronises the stream. */

@@ -57,6 +57,12 @@ constexpr int sweep_block(int key_bytes, int value_bytes) {
 }
 constexpr int kHistBlock = 1024;
 constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-byte descriptor
+// The per-XCD tile order (rsort_kernels.hpp) lets a tile wait for a tile whose workgroup has not been launched yet.  One
+// sort alone always gets that workgroup launched (each XCD has free slots whenever it is behind), but several LARGE sorts
+// running on one GPU at the same time could fill each other's slots with waiting workgroups.  So the order is used only
+// where it pays -- sorts of at least this many tiles (16 M four-byte keys), which saturate the GPU on their own -- and
+// rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
+constexpr size_t kPerXcdMinTiles = 1024;
 
 struct DevBuf {
   void* p = nullptr;
@@ -73,7 +79,8 @@ struct rs_ctx {
   // ctrl layout: [0, 16K) ghist  u64[8][256]; [16K, 32K) gbase u64[8][256];
   //              [32K, 32K+64) tickets u32[16]; [32K+64, 32K+128) error flag (+pad)
   bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
-  bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create
+  bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create (and cleared by rs_ctx_set_tile_order)
+  bool per_xcd_probe_ok = false;     // what the probe found
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   hipEvent_t ev[kMaxPasses + 2] = {};
@@ -373,7 +380,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.fmask_out = done == n_live - 1 ? fmask : 0; a.smask_out = done == n_live - 1 ? smask : 0;  // last launched pass
     a.shift = begin_bit + p * rsk::kRadixBits;
     a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
-    a.per_xcd_order = c->per_xcd_order ? 1 : 0;
+    a.per_xcd_order = c->per_xcd_order && tiles >= kPerXcdMinTiles ? 1 : 0;
     a.incl_code = 2u + (done & 1);          // alternates over the LAUNCHED passes (descriptor parity, rsort_kernels.hpp)
     launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, s);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
@@ -463,6 +470,7 @@ int rs_ctx_create(rs_ctx** out, int device) {
       (void)hipFree(d_cnt);
       for (unsigned x = 0; ok && x < rsk::kXcds; ++x) ok = h_cnt[x] >= 1024 / rsk::kXcds / 2;
       c->per_xcd_order = ok;
+      c->per_xcd_probe_ok = ok;
     }
   }
   *out = c;
@@ -510,6 +518,12 @@ int rs_ctx_synchronize(rs_ctx* c) {
 int rs_ctx_set_precheck(rs_ctx* c, int enabled) {
   if (!c) return RS_ERR_ARG;
   c->precheck = enabled != 0;
+  return RS_OK;
+}
+
+int rs_ctx_set_tile_order(rs_ctx* c, int per_xcd) {
+  if (!c) return RS_ERR_ARG;
+  c->per_xcd_order = per_xcd != 0 && c->per_xcd_probe_ok;   // never on a device the probe rejected
   return RS_OK;
 }
 
@@ -604,7 +618,7 @@ int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, cons
   a.n = n;
   a.fmask_in = fmask; a.smask_in = smask; a.fmask_out = fmask; a.smask_out = smask;   // ordered on the transformed digit, stored as they came
   a.shift = begin_bit; a.bits = end_bit - begin_bit;
-  a.per_xcd_order = c->per_xcd_order ? 1 : 0;
+  a.per_xcd_order = c->per_xcd_order && tiles >= kPerXcdMinTiles ? 1 : 0;
   a.incl_code = 2u;
   launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, s);
   RS_HIP(c, hipGetLastError());

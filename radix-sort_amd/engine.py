@@ -50,6 +50,9 @@ class Engine:
     def set_precheck(self, on: bool):
         self._ck(self.lib.rs_ctx_set_precheck(self.h, int(on)))
 
+    def set_tile_order(self, per_xcd: bool):
+        self._ck(self.lib.rs_ctx_set_tile_order(self.h, int(per_xcd)))
+
     def set_profiling(self, on: bool):
         self._ck(self.lib.rs_ctx_set_profiling(self.h, int(on)))
 

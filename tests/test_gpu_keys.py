@@ -197,3 +197,21 @@ def test_small_kernel_sizes_and_bit_ranges(engine, oracle, name):
         field = (v.astype(np.uint64) >> np.uint64(4)) & np.uint64((1 << (kb * 8 - 7)) - 1)
         want = v[np.argsort(field, kind="stable")]
         assert t.cpu().numpy().tobytes() == want.tobytes(), name
+
+
+@pytest.mark.parametrize("name,n", [("u32", 1024 * 16384 + 12345), ("i64", 1030 * 8192 + 77), ("f32", 1087 * 16384)])
+def test_per_xcd_tile_order_sizes(engine, oracle, name, n):
+    """Sorts of at least 1024 tiles draw their tiles from one ticket counter per XCD (groups of 8 consecutive tiles);
+    sizes that leave a partial last group make workgroups draw from other XCDs' counters.  Also with the order
+    switched off through rs_ctx_set_tile_order."""
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    v = shapes.generate(name, n, "randomized", seed=11)
+    want = oracle.sort_keys(v, xf, mt=True).tobytes()
+    engine.set_precheck(False)
+    try:
+        assert engine.sort_keys_host(v, xf).tobytes() == want
+        engine.set_tile_order(False)
+        assert engine.sort_keys_host(v, xf).tobytes() == want
+    finally:
+        engine.set_tile_order(True)
+        engine.set_precheck(True)
