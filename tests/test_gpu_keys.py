@@ -215,3 +215,34 @@ def test_per_xcd_tile_order_sizes(engine, oracle, name, n):
     finally:
         engine.set_tile_order(True)
         engine.set_precheck(True)
+
+
+def test_concurrent_sorts_on_two_contexts(oracle):
+    """Two host threads, each with its own context (= its own stream), sorting at the same time on one GPU: the
+    look-back of one sort must not depend on anything the other one holds.  Sizes below 1024 tiles (single ticket
+    counter) and, with the per-XCD order switched off as rsort_hip.h asks of concurrent callers, above."""
+    import threading
+    import radix_sort_amd as rs
+    errors = []
+
+    def worker(seed, sizes, tile_order):
+        try:
+            eng = rs.Engine(0)
+            eng.set_precheck(False)
+            eng.set_tile_order(tile_order)
+            for j, n in enumerate(sizes):
+                v = shapes.generate("u32", n, "randomized", seed=seed * 100 + j)
+                got = eng.sort_keys_host(v, 0)
+                if got.tobytes() != np.sort(v).tobytes():
+                    errors.append((seed, n))
+            eng.close()
+        except Exception as e:            # noqa: BLE001 -- reported through the assertion below
+            errors.append((seed, repr(e)))
+
+    for sizes, tile_order in (([3_000_000, 1_500_001, 5_000_000, 700_000] * 2, True), ([20_000_000, 18_000_001], False)):
+        threads = [threading.Thread(target=worker, args=(s, sizes, tile_order)) for s in (1, 2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
