@@ -341,7 +341,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   int ev = 0;
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
   RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlBytes, s));
-  RS_HIP(c, hipMemsetAsync(c->desc.p, 0, desc_bytes_for(n), s));
+  RS_HIP(c, hipMemsetAsync(c->desc.p, 0, tiles * 256 * (wide ? 8 : 4), s));   // the rows this sort uses, not the whole reservation
 
   rsk::HistArgs h{};
   h.keys = keys; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
