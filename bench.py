@@ -111,12 +111,13 @@ def bench_single(args):
             if not pass_ms:                           # ordered input: also time the sort engine proper
                 full = timed(False)
             # size-independent parity property at full size: sortedness + checksum (sum of bits)
-            if kb == 4:
-                okey = work if xf == 1 else work ^ (-(1 << 31))       # unsigned order via sign flip
-            else:
-                okey = work if xf == 1 else work ^ (-(1 << 63))
-            if xf == 2:
-                raise NotImplementedError("float order check lives in tests/")
+            sign = -(1 << 31) if kb == 4 else -(1 << 63)
+            if xf == 1:
+                okey = work                                            # two's complement: signed compare as is
+            elif xf == 0:
+                okey = work ^ sign                                     # unsigned order via sign flip
+            else:                                                      # IEEE-754 bits: negatives reverse (radix_sort.hpp:405)
+                okey = torch.where(work < 0, ~work ^ sign, work)
             sorted_ok = bool((okey[1:] >= okey[:-1]).all().item())
             sum_ok = bool((work.sum() == src.sum()).item())
             del okey
