@@ -50,7 +50,9 @@ int rs_ctx_create(rs_ctx** out, int device);
 int rs_ctx_destroy(rs_ctx* ctx);
 const char* rs_last_error(const rs_ctx* ctx);
 
-/* Attach a caller-owned hipStream_t (passed as void*; NULL = the context's own stream). */
+/* Attach a caller-owned hipStream_t (passed as void*; NULL = the context's own stream -- HIP's default stream also has
+ * handle NULL, so it cannot be attached: wait for work queued there before sorting data it produces).  Keys must not
+ * change while a sort runs on them; if they do the call reports RS_ERR_KERNEL at the next synchronisation. */
 int rs_ctx_set_stream(rs_ctx* ctx, void* hip_stream);
 /* Pre-size the workspace for n keys of key_bytes with value_bytes payload (0 = keys only), so that
  * later sorts up to that size do not allocate. */

@@ -403,6 +403,9 @@ int check_kernel_error(rs_ctx* c) {
   if (!ctrl) return RS_OK;
   RS_HIP(c, hipMemcpyAsync(&flag, ctrl + kCtrlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
   RS_HIP(c, hipStreamSynchronize(c->stream));
+  if (flag == 2)
+    return fail(c, RS_ERR_KERNEL, "an output offset fell outside the array: the keys changed while the sort was running "
+                                  "(the stream that produces them was not waited for?); the result is not a sort of the input");
   if (flag) return fail(c, RS_ERR_KERNEL, "onesweep look-back timed out (descriptor chain broken)");
   return RS_OK;
 }

@@ -35,8 +35,6 @@
 // Diagnostic builds only, never defined in the product:
 //   -DRS_STAMPS   wave 0 / lane 0 of every 64th tile stores s_memrealtime (100 MHz) at phase
 //                 boundaries into a buffer no other code reads;
-//   -DRS_CHECKED  every output offset is range-checked; a bad one sets the error flag instead of
-//                 storing.
 #ifdef RS_STAMPS
 __device__ unsigned long long rs_stamp_buf[16 * 4096];
 #define RS_STAMP(slot)                                                                        \
@@ -741,11 +739,12 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     if (full || j < tile_count) {
       K k = stage_k[stage_swizzle(j)];
       D o = s.gofs[digit_at(k, a.shift, a.bits)] + j;
-#ifdef RS_CHECKED
-      if (static_cast<uint64_t>(o) >= a.n) { __hip_atomic_store(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); continue; }
-#endif
-      kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
-      if constexpr (HAS_VAL) dst[i] = o;
+      // Offsets come from the up-front histogram; keys that change while the sort runs (a caller that did not wait for
+      // whatever produces them) make the two disagree.  Such an offset is reported, never written through.
+      const bool inside = static_cast<uint64_t>(o) < a.n;
+      if (inside) kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
+      else __hip_atomic_store(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (HAS_VAL) dst[i] = inside ? o : ~static_cast<D>(0);
     }
   }
 #ifdef RS_STAMPS
@@ -771,7 +770,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       unsigned j = i * BLOCK + tid;
-      if (full || j < tile_count) vout[dst[i]] = stage_v[j];
+      if ((full || j < tile_count) && dst[i] != ~static_cast<D>(0)) vout[dst[i]] = stage_v[j];
     }
   }
 }

@@ -201,6 +201,14 @@ class HipLocal:
     def synchronize(self):
         self.eng.synchronize()
 
+    def wait_for_producers(self, t):
+        """The engine sorts on ITS stream (a context given stream handle 0 -- torch's default stream -- uses its own, see
+        rs_ctx_set_stream); whatever produced `t` on torch's streams (a copy, an RCCL collective) has to be finished
+        before the engine reads it: sorting keys that are still being written breaks the histogram the scatter relies on."""
+        import torch
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+
 
 # ---------------------------------------------------------------------------------------------
 # the distributed sort
@@ -216,6 +224,7 @@ def distributed_sort(keys, local, comm: Comm, values=None):
     indices this is the permutation the reference's projected sort applies (radix_sort.hpp:1111-1154)."""
     world = comm.world
     n = keys.numel()
+    local.wait_for_producers(keys)
     if world == 1:
         local.sort(keys, None, values, None)
         local.synchronize()
@@ -260,7 +269,8 @@ def distributed_sort(keys, local, comm: Comm, values=None):
         vrecv = local.empty_like(values, int(recv_counts.sum()))
         comm.all_to_all(values, send_counts, recv_counts, vrecv)
 
-    # 6. local LSD sort of the received range
+    # 6. local LSD sort of the received range (once the exchange has delivered it)
+    local.wait_for_producers(recv)
     local.sort(recv, scratch, vrecv, vscratch)
     local.synchronize()
     return recv if values is None else (recv, vrecv)

@@ -38,7 +38,10 @@ class Engine:
             raise _lib.RsortError(rc, self.lib.rs_last_error(self.h).decode())
 
     def set_stream(self, stream):
-        """stream: a raw hipStream_t integer (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        """stream: a raw hipStream_t integer (e.g. torch.cuda.current_stream().cuda_stream) or None.
+        Handle 0 / None -- which is also what torch's DEFAULT stream reports -- selects the context's own stream, so work
+        queued by torch on its default stream is NOT ordered before the sort: wait for it first
+        (torch.cuda.current_stream().synchronize()), as bench.py and dist.py do."""
         self._ck(self.lib.rs_ctx_set_stream(self.h, C.c_void_p(stream or None)))
 
     def reserve(self, n, key_bytes, value_bytes=0):

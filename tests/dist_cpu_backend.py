@@ -64,3 +64,6 @@ class NumpyLocal:
 
     def synchronize(self):
         pass
+
+    def wait_for_producers(self, t):
+        pass
