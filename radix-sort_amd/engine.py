@@ -23,6 +23,7 @@ class Engine:
             raise _lib.RsortError(rc, f"rs_ctx_create(device={device}) failed (no usable GPU?)")
         self.h = h
         self.device = device
+        self._own_stream = True
         if stream is not None:
             self.set_stream(stream)
 
@@ -43,6 +44,14 @@ class Engine:
         queued by torch on its default stream is NOT ordered before the sort: wait for it first
         (torch.cuda.current_stream().synchronize()), as bench.py and dist.py do."""
         self._ck(self.lib.rs_ctx_set_stream(self.h, C.c_void_p(stream or None)))
+        self._own_stream = not stream
+
+    def _wait_for_torch(self, t):
+        """Tensor entry points only: when the sort runs on the context's own stream, what torch queued for this tensor
+        must have finished (a sort of keys that are still being written scatters to offsets its histogram never saw)."""
+        if self._own_stream:
+            import torch
+            torch.cuda.current_stream(t.device).synchronize()
 
     def reserve(self, n, key_bytes, value_bytes=0):
         self._ck(self.lib.rs_ctx_reserve(self.h, n, key_bytes, value_bytes))
@@ -100,12 +109,14 @@ class Engine:
     def sort_keys_(self, t, transform, alt=None, begin_bit=0, end_bit=None):
         """In-place sort of a contiguous 1-D device tensor whose element size is the key width."""
         assert t.is_cuda and t.is_contiguous() and t.dim() == 1
+        self._wait_for_torch(t)
         self.sort_keys_ptr(t.data_ptr(), t.numel(), t.element_size(), transform,
                            alt.data_ptr() if alt is not None else None, begin_bit, end_bit)
         return t
 
     def sort_pairs_(self, k, v, transform, alt_k=None, alt_v=None, begin_bit=0, end_bit=None):
         assert k.is_cuda and v.is_cuda and k.is_contiguous() and v.is_contiguous() and k.numel() == v.numel()
+        self._wait_for_torch(k)
         self.sort_pairs_ptr(k.data_ptr(), v.data_ptr(), k.numel(), k.element_size(), v.element_size(), transform,
                             alt_k.data_ptr() if alt_k is not None else None,
                             alt_v.data_ptr() if alt_v is not None else None, begin_bit, end_bit)
