@@ -208,6 +208,7 @@ namespace radix_sort
 				PackedStrings p = packStrings(v, proj, threads);
 				std::vector<std::uint64_t> perm(v.size());
 				rs_ctx* ctx = context();
+				check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(threads)));
 				check(ctx, rs_sort_strings(ctx, p.blob.data(), p.offsets.data(), v.size(), perm.data(), stable ? 1 : 0));
 				applyPermutation(v, perm, threads);
 			}
@@ -232,6 +233,7 @@ namespace radix_sort
 						"ERROR: Unable to sort vector! CAUSE: std::vector<bool> has no element storage!");
 					device::checkKeyType<T>();
 					rs_ctx* ctx = device::context();
+					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(device::hostThreads(v.size(), enableMultiThreading))));
 					device::check(ctx, rs_sort_keys(ctx, v.data(), v.size(), static_cast<int>(sizeof(T)),
 						device::transformOf<T>(), 0, static_cast<int>(sizeof(T)) * 8));
 				}
@@ -265,6 +267,7 @@ namespace radix_sort
 					});
 
 					rs_ctx* ctx = device::context();
+					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(threads)));
 					constexpr int XF = device::transformOf<Key>();
 					constexpr int BITS = static_cast<int>(sizeof(Key)) * 8;
 

@@ -78,6 +78,12 @@ int rs_ctx_set_precheck(rs_ctx* ctx, int enabled);
  * No counterpart in the reference (a CPU library). */
 int rs_ctx_set_tile_order(rs_ctx* ctx, int per_xcd);
 
+/* Host threads the entry points that take HOST buffers (rs_sort_keys, rs_sort_pairs, rs_sort_strings) may use to move
+ * the arrays to the GPU and back (default 1 = the calling thread only; at most 4 are used).  Arrays of 1 MiB and more
+ * travel through pinned bounce buffers, one pipeline per thread; the front-end passes the reference's own thread rule
+ * here (getNumOfThreads radix_sort.hpp:112-123: 1 unless the caller asked for multi-threading and n >= 2,000,000). */
+int rs_ctx_set_host_threads(rs_ctx* ctx, int threads);
+
 /* Per-kernel timing with HIP events on the context's stream (for bench.py's roofline block).
  * After a sort with profiling on, rs_ctx_get_profile fills ms[0] = histogram+scan,
  * ms[1..passes] = the onesweep passes in order; *count = 1 + passes.  Synchronises the stream. */

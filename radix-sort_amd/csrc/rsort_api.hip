@@ -15,6 +15,7 @@
 #include <string>
 #include <type_traits>
 
+#include "rsort_transfer.hpp"
 #include "rsort_kernels.hpp"
 #include "rsort_strings.hpp"
 
@@ -85,6 +86,7 @@ struct rs_ctx {
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   hipEvent_t ev[kMaxPasses + 2] = {};
   int ev_count = 0;
+  rst::Mover mover;        // host <-> HBM legs of the host-buffer entry points (rsort_transfer.hpp)
   std::string err;
 };
 
@@ -410,6 +412,29 @@ int check_kernel_error(rs_ctx* c) {
   return RS_OK;
 }
 
+// Host array -> HBM before a sort.  Small arrays: one pageable copy on the sort's stream.  Large ones: the mover's lanes,
+// once everything queued on the stream (which may still use the workspace) has drained.
+int to_device(rs_ctx* c, void* d, const void* h, size_t bytes) {
+  if (bytes < rst::kStagedMin) {
+    RS_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return RS_OK;
+  }
+  RS_HIP(c, hipStreamSynchronize(c->stream));
+  RS_HIP(c, c->mover.move(c->device, static_cast<char*>(const_cast<void*>(h)), static_cast<char*>(d), bytes, true));
+  return RS_OK;
+}
+// HBM -> host array after a sort; the caller finishes with check_kernel_error (which also waits for the small-array copy).
+int to_host(rs_ctx* c, void* h, const void* d, size_t bytes) {
+  if (bytes < rst::kStagedMin) {
+    RS_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    return RS_OK;
+  }
+  int rc = check_kernel_error(c);          // the sort has finished, and finished well, before its result is fetched
+  if (rc != RS_OK) return rc;
+  RS_HIP(c, c->mover.move(c->device, static_cast<char*>(h), static_cast<char*>(const_cast<void*>(d)), bytes, false));
+  return RS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -488,6 +513,7 @@ int rs_ctx_destroy(rs_ctx* c) {
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  c->mover.release_all();
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return RS_OK;
@@ -527,6 +553,13 @@ int rs_ctx_set_precheck(rs_ctx* c, int enabled) {
 int rs_ctx_set_tile_order(rs_ctx* c, int per_xcd) {
   if (!c) return RS_ERR_ARG;
   c->per_xcd_order = per_xcd != 0 && c->per_xcd_probe_ok;   // never on a device the probe rejected
+  return RS_OK;
+}
+
+int rs_ctx_set_host_threads(rs_ctx* c, int threads) {
+  if (!c) return RS_ERR_ARG;
+  if (threads < 1) return fail(c, RS_ERR_ARG, "host threads must be >= 1");
+  c->mover.host_threads = threads;      // the mover uses at most rst::kMaxLanes of them
   return RS_OK;
 }
 
@@ -638,10 +671,10 @@ int rs_sort_keys(rs_ctx* c, void* h_keys, size_t n, int key_bytes, int transform
   const size_t padded = (bytes + 255) & ~size_t(255);
   if ((rc = ensure(c, c->alt_keys, 2 * padded)) != RS_OK) return rc;
   char* d = static_cast<char*>(c->alt_keys.p);
-  RS_HIP(c, hipMemcpyAsync(d, h_keys, bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = to_device(c, d, h_keys, bytes)) != RS_OK) return rc;
   if ((rc = sort_device(c, d, nullptr, d + padded, nullptr, n, key_bytes, 0, transform, begin_bit, end_bit)) != RS_OK)
     return rc;
-  RS_HIP(c, hipMemcpyAsync(h_keys, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = to_host(c, h_keys, d, bytes)) != RS_OK) return rc;
   return check_kernel_error(c);
 }
 
@@ -659,12 +692,12 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
   if ((rc = ensure(c, c->alt_vals, 2 * vpad)) != RS_OK) return rc;
   char* dk = static_cast<char*>(c->alt_keys.p);
   char* dv = static_cast<char*>(c->alt_vals.p);
-  RS_HIP(c, hipMemcpyAsync(dk, h_keys, kb, hipMemcpyHostToDevice, c->stream));
-  RS_HIP(c, hipMemcpyAsync(dv, h_values, vb, hipMemcpyHostToDevice, c->stream));
+  if ((rc = to_device(c, dk, h_keys, kb)) != RS_OK) return rc;
+  if ((rc = to_device(c, dv, h_values, vb)) != RS_OK) return rc;
   if ((rc = sort_device(c, dk, dv, dk + kpad, dv + vpad, n, key_bytes, value_bytes, transform, begin_bit, end_bit)) != RS_OK)
     return rc;
-  RS_HIP(c, hipMemcpyAsync(h_keys, dk, kb, hipMemcpyDeviceToHost, c->stream));
-  RS_HIP(c, hipMemcpyAsync(h_values, dv, vb, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = to_host(c, h_keys, dk, kb)) != RS_OK) return rc;
+  if ((rc = to_host(c, h_values, dv, vb)) != RS_OK) return rc;
   return check_kernel_error(c);
 }
 
@@ -729,8 +762,8 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
            *ids2 = u[7], *pos = u[8], *pos2 = u[9], *head = u[10], *scan_a = u[11], *scan_b = u[12];
   auto* block_sums = reinterpret_cast<uint32_t*>(take((blocks0 + 2) * 4));
 
-  if (total) RS_HIP(c, hipMemcpyAsync(d_blob, h_blob, total, hipMemcpyHostToDevice, s));
-  RS_HIP(c, hipMemcpyAsync(d_off, h_offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
+  if (total && (rc = to_device(c, d_blob, h_blob, total)) != RS_OK) return rc;
+  if ((rc = to_device(c, d_off, h_offsets, (n + 1) * 8)) != RS_OK) return rc;
 
   auto grid = [](size_t m) { return dim3(static_cast<unsigned>((m + rss::kBlock - 1) / rss::kBlock)); };
   auto scan = [&](const uint32_t* in, size_t m, uint32_t* out, bool inclusive) {
@@ -782,7 +815,7 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
   c->profiling = prof;
   RS_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(rss::widen_kernel, grid(n), dim3(rss::kBlock), 0, s, perm, static_cast<uint32_t>(n), keys);
-  RS_HIP(c, hipMemcpyAsync(h_perm, keys, n * 8, hipMemcpyDeviceToHost, s));
+  if ((rc = to_host(c, h_perm, keys, n * 8)) != RS_OK) return rc;
   return check_kernel_error(c);
 }
 

@@ -65,6 +65,10 @@ class Engine:
     def set_tile_order(self, per_xcd: bool):
         self._ck(self.lib.rs_ctx_set_tile_order(self.h, int(per_xcd)))
 
+    def set_host_threads(self, threads: int):
+        """Threads the host-buffer entry points may use for the transfers (default 1; at most 4 are used)."""
+        self._ck(self.lib.rs_ctx_set_host_threads(self.h, int(threads)))
+
     def set_profiling(self, on: bool):
         self._ck(self.lib.rs_ctx_set_profiling(self.h, int(on)))
 
