@@ -49,6 +49,13 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`. "
                 "There is no CPU fallback for the sort path.")
+        # torch ships a HIP/HSA runtime of its own (torch/lib).  Whichever runtime a process loads first is the one that sees
+        # the GPU: with /opt/rocm's loaded first (through this library), a later `import torch` finds no device.  So when
+        # torch is installed it goes first, and this library binds to the runtime torch brought.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
