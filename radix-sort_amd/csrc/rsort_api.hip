@@ -87,6 +87,7 @@ struct rs_ctx {
   hipEvent_t ev[kMaxPasses + 2] = {};
   int ev_count = 0;
   rst::Mover mover;        // host <-> HBM legs of the host-buffer entry points (rsort_transfer.hpp)
+  struct Fetched { void* host; size_t bytes; } fetched[2] = {{nullptr, 0}, {nullptr, 0}};   // small results waiting in pinned memory
   std::string err;
 };
 
@@ -402,7 +403,10 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
 int check_kernel_error(rs_ctx* c) {
   unsigned flag = 0;
   char* ctrl = static_cast<char*>(c->ctrl.p);
-  if (!ctrl) return RS_OK;
+  if (!ctrl) {                             // only single-workgroup sorts so far: no error word yet, but still a wait
+    RS_HIP(c, hipStreamSynchronize(c->stream));
+    return RS_OK;
+  }
   RS_HIP(c, hipMemcpyAsync(&flag, ctrl + kCtrlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
   RS_HIP(c, hipStreamSynchronize(c->stream));
   if (flag == 2)
@@ -414,25 +418,63 @@ int check_kernel_error(rs_ctx* c) {
 
 // Host array -> HBM before a sort.  Small arrays: one pageable copy on the sort's stream.  Large ones: the mover's lanes,
 // once everything queued on the stream (which may still use the workspace) has drained.
-int to_device(rs_ctx* c, void* d, const void* h, size_t bytes) {
-  if (bytes < rst::kStagedMin) {
+bool staged_transfers() {                  // RSORT_STAGED=0: plain pageable copies on the sort's stream (A/B timing, tests)
+  static const bool on = [] { const char* e = std::getenv("RSORT_STAGED"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// Host array -> HBM before a sort; `slot` (0 or 1) names the bounce buffer an array of less than 1 MiB goes through, so
+// the two arrays of one call (keys and payload, blob and offsets) use different ones.
+//   small arrays: memcpy into lane 0's pinned buffer, then one DMA on the sort's own stream (nothing to wait for);
+//   large arrays: the mover's lanes, once everything queued on the stream (which may still use the workspace) has drained.
+int to_device(rs_ctx* c, void* d, const void* h, size_t bytes, int slot) {
+  if (!staged_transfers()) {
     RS_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+    return RS_OK;
+  }
+  if (bytes < rst::kStagedMin) {
+    rst::Lane& L = c->mover.lanes[0];
+    RS_HIP(c, c->mover.prepare(L));
+    std::memcpy(L.pinned[slot], h, bytes);
+    RS_HIP(c, hipMemcpyAsync(d, L.pinned[slot], bytes, hipMemcpyHostToDevice, c->stream));
     return RS_OK;
   }
   RS_HIP(c, hipStreamSynchronize(c->stream));
   RS_HIP(c, c->mover.move(c->device, static_cast<char*>(const_cast<void*>(h)), static_cast<char*>(d), bytes, true));
   return RS_OK;
 }
-// HBM -> host array after a sort; the caller finishes with check_kernel_error (which also waits for the small-array copy).
-int to_host(rs_ctx* c, void* h, const void* d, size_t bytes) {
-  if (bytes < rst::kStagedMin) {
+// what to_host fetched into pinned memory goes to the caller's arrays (the stream has been waited for)
+void hand_over(rs_ctx* c) {
+  for (int slot = 0; slot < 2; ++slot) {
+    if (c->fetched[slot].host) std::memcpy(c->fetched[slot].host, c->mover.lanes[0].pinned[slot], c->fetched[slot].bytes);
+    c->fetched[slot] = {nullptr, 0};
+  }
+}
+// HBM -> host array after a sort.  Small arrays are fetched into the pinned buffer on the sort's stream and handed to the
+// caller by finish_host_call; large ones are moved here, after the sort has finished and finished well.
+int to_host(rs_ctx* c, void* h, const void* d, size_t bytes, int slot) {
+  if (!staged_transfers()) {
     RS_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     return RS_OK;
   }
-  int rc = check_kernel_error(c);          // the sort has finished, and finished well, before its result is fetched
+  if (bytes < rst::kStagedMin) {
+    rst::Lane& L = c->mover.lanes[0];
+    RS_HIP(c, c->mover.prepare(L));
+    RS_HIP(c, hipMemcpyAsync(L.pinned[slot], d, bytes, hipMemcpyDeviceToHost, c->stream));
+    c->fetched[slot] = {h, bytes};
+    return RS_OK;
+  }
+  int rc = check_kernel_error(c);
   if (rc != RS_OK) return rc;
+  hand_over(c);                            // a small array of the same call sits in the buffers the lanes are about to reuse
   RS_HIP(c, c->mover.move(c->device, static_cast<char*>(h), static_cast<char*>(const_cast<void*>(d)), bytes, false));
   return RS_OK;
+}
+// Last step of a host-buffer entry point: wait, report a kernel fault, hand over what to_host fetched into pinned memory.
+int finish_host_call(rs_ctx* c) {
+  int rc = check_kernel_error(c);
+  if (rc == RS_OK) hand_over(c);
+  c->fetched[0] = c->fetched[1] = {nullptr, 0};
+  return rc;
 }
 
 }  // namespace
@@ -665,17 +707,18 @@ int rs_sort_keys(rs_ctx* c, void* h_keys, size_t n, int key_bytes, int transform
   int rc = check_args(c, h_keys, n, key_bytes, 0, transform, begin_bit, end_bit);
   if (rc != RS_OK) return rc;
   if (n < 2) return RS_OK;
+  c->fetched[0] = c->fetched[1] = {nullptr, 0};   // nothing left over from a call that failed half-way
   RS_HIP(c, hipSetDevice(c->device));
   // device layout: [keys | alt] in the workspace's alt_keys buffer
   const size_t bytes = n * key_bytes;
   const size_t padded = (bytes + 255) & ~size_t(255);
   if ((rc = ensure(c, c->alt_keys, 2 * padded)) != RS_OK) return rc;
   char* d = static_cast<char*>(c->alt_keys.p);
-  if ((rc = to_device(c, d, h_keys, bytes)) != RS_OK) return rc;
+  if ((rc = to_device(c, d, h_keys, bytes, 0)) != RS_OK) return rc;
   if ((rc = sort_device(c, d, nullptr, d + padded, nullptr, n, key_bytes, 0, transform, begin_bit, end_bit)) != RS_OK)
     return rc;
-  if ((rc = to_host(c, h_keys, d, bytes)) != RS_OK) return rc;
-  return check_kernel_error(c);
+  if ((rc = to_host(c, h_keys, d, bytes, 0)) != RS_OK) return rc;
+  return finish_host_call(c);
 }
 
 int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_bytes, int value_bytes, int transform,
@@ -685,6 +728,7 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
   if (value_bytes == 0) return fail(c, RS_ERR_ARG, "value_bytes must be 4 or 8");
   if (n > 0 && !h_values) return fail(c, RS_ERR_ARG, "null value pointer");
   if (n < 2) return RS_OK;
+  c->fetched[0] = c->fetched[1] = {nullptr, 0};   // nothing left over from a call that failed half-way
   RS_HIP(c, hipSetDevice(c->device));
   const size_t kb = n * key_bytes, vb = n * value_bytes;
   const size_t kpad = (kb + 255) & ~size_t(255), vpad = (vb + 255) & ~size_t(255);
@@ -692,13 +736,13 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
   if ((rc = ensure(c, c->alt_vals, 2 * vpad)) != RS_OK) return rc;
   char* dk = static_cast<char*>(c->alt_keys.p);
   char* dv = static_cast<char*>(c->alt_vals.p);
-  if ((rc = to_device(c, dk, h_keys, kb)) != RS_OK) return rc;
-  if ((rc = to_device(c, dv, h_values, vb)) != RS_OK) return rc;
+  if ((rc = to_device(c, dk, h_keys, kb, 0)) != RS_OK) return rc;
+  if ((rc = to_device(c, dv, h_values, vb, 1)) != RS_OK) return rc;
   if ((rc = sort_device(c, dk, dv, dk + kpad, dv + vpad, n, key_bytes, value_bytes, transform, begin_bit, end_bit)) != RS_OK)
     return rc;
-  if ((rc = to_host(c, h_keys, dk, kb)) != RS_OK) return rc;
-  if ((rc = to_host(c, h_values, dv, vb)) != RS_OK) return rc;
-  return check_kernel_error(c);
+  if ((rc = to_host(c, h_keys, dk, kb, 0)) != RS_OK) return rc;
+  if ((rc = to_host(c, h_values, dv, vb, 1)) != RS_OK) return rc;
+  return finish_host_call(c);
 }
 
 
@@ -739,6 +783,7 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
   if (n == 1) { h_perm[0] = 0; return RS_OK; }
   const uint64_t total = h_offsets[n];
   if (total > 0 && !h_blob) return fail(c, RS_ERR_ARG, "null blob pointer");
+  c->fetched[0] = c->fetched[1] = {nullptr, 0};   // nothing left over from a call that failed half-way
   RS_HIP(c, hipSetDevice(c->device));
   hipStream_t s = c->stream;
 
@@ -762,8 +807,8 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
            *ids2 = u[7], *pos = u[8], *pos2 = u[9], *head = u[10], *scan_a = u[11], *scan_b = u[12];
   auto* block_sums = reinterpret_cast<uint32_t*>(take((blocks0 + 2) * 4));
 
-  if (total && (rc = to_device(c, d_blob, h_blob, total)) != RS_OK) return rc;
-  if ((rc = to_device(c, d_off, h_offsets, (n + 1) * 8)) != RS_OK) return rc;
+  if (total && (rc = to_device(c, d_blob, h_blob, total, 0)) != RS_OK) return rc;
+  if ((rc = to_device(c, d_off, h_offsets, (n + 1) * 8, 1)) != RS_OK) return rc;
 
   auto grid = [](size_t m) { return dim3(static_cast<unsigned>((m + rss::kBlock - 1) / rss::kBlock)); };
   auto scan = [&](const uint32_t* in, size_t m, uint32_t* out, bool inclusive) {
@@ -815,8 +860,8 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
   c->profiling = prof;
   RS_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(rss::widen_kernel, grid(n), dim3(rss::kBlock), 0, s, perm, static_cast<uint32_t>(n), keys);
-  if ((rc = to_host(c, h_perm, keys, n * 8)) != RS_OK) return rc;
-  return check_kernel_error(c);
+  if ((rc = to_host(c, h_perm, keys, n * 8, 0)) != RS_OK) return rc;
+  return finish_host_call(c);
 }
 
 }  // extern "C"

@@ -18,7 +18,8 @@
 
 namespace rst {
 
-constexpr size_t kChunk = size_t(4) << 20;
+constexpr size_t kChunk = size_t(4) << 20;        // bounce buffer size = largest piece
+constexpr size_t kMinPiece = size_t(256) << 10;   // smallest piece: short arrays still get a pipeline of several steps
 constexpr int kMaxLanes = 4;                       // two already saturate the link; four cover slower host memory
 constexpr size_t kStagedMin = size_t(1) << 20;     // below this one pageable copy on the sort's stream is the quicker way
 
@@ -54,11 +55,11 @@ struct Mover {
   void release_all() { for (auto& L : lanes) release(L); }
 
   // bytes [lo, hi) of the array, host -> device
-  static hipError_t up(Lane& L, const char* host, char* dev, size_t lo, size_t hi) {
+  static hipError_t up(Lane& L, const char* host, char* dev, size_t lo, size_t hi, size_t piece) {
     hipError_t e = hipSuccess;
     int b = 0;
-    for (size_t at = lo; at < hi && e == hipSuccess; at += kChunk, b ^= 1) {
-      const size_t len = std::min(kChunk, hi - at);
+    for (size_t at = lo; at < hi && e == hipSuccess; at += piece, b ^= 1) {
+      const size_t len = std::min(piece, hi - at);
       e = hipEventSynchronize(L.done[b]);                          // the DMA that last read this bounce buffer
       if (e != hipSuccess) break;
       std::memcpy(L.pinned[b], host + at, len);
@@ -69,7 +70,7 @@ struct Mover {
     return e != hipSuccess ? e : s;
   }
   // bytes [lo, hi) of the array, device -> host: the DMA of one chunk runs while the previous one is copied out
-  static hipError_t down(Lane& L, char* host, const char* dev, size_t lo, size_t hi) {
+  static hipError_t down(Lane& L, char* host, const char* dev, size_t lo, size_t hi, size_t piece) {
     hipError_t e = hipSuccess;
     size_t pend_at[2] = {0, 0}, pend_len[2] = {0, 0};
     int b = 0;
@@ -81,7 +82,7 @@ struct Mover {
         pend_len[b] = 0;
       }
       if (at < hi) {
-        const size_t len = std::min(kChunk, hi - at);
+        const size_t len = std::min(piece, hi - at);
         e = hipMemcpyAsync(L.pinned[b], dev + at, len, hipMemcpyDeviceToHost, L.stream);
         if (e == hipSuccess) e = hipEventRecord(L.done[b], L.stream);
         pend_at[b] = at; pend_len[b] = len;
@@ -95,17 +96,19 @@ struct Mover {
   // Moves the whole array and returns when it has arrived.  The caller has made sure nothing queued elsewhere still
   // uses the device range (to_device) or still writes it (from device).
   hipError_t move(int device, char* host, char* dev, size_t bytes, bool to_device) {
-    const size_t chunks = (bytes + kChunk - 1) / kChunk;
-    const int lanes_used = static_cast<int>(std::min<size_t>({static_cast<size_t>(std::max(host_threads, 1)), size_t(kMaxLanes), chunks}));
+    const size_t most = (bytes + kMinPiece - 1) / kMinPiece;                     // no lane for less than one small piece
+    const int lanes_used = static_cast<int>(std::min<size_t>({static_cast<size_t>(std::max(host_threads, 1)), size_t(kMaxLanes), most}));
     for (int t = 0; t < lanes_used; ++t) {
       hipError_t e = prepare(lanes[t]);
       if (e != hipSuccess) return e;
     }
-    const size_t per = ((chunks + lanes_used - 1) / lanes_used) * kChunk;      // whole chunks per lane
+    // each lane's share in about eight pieces, between 256 KiB and the bounce buffer size, in whole 64 KiB units
+    const size_t per = (((bytes + lanes_used - 1) / lanes_used) + 65535) & ~size_t(65535);
+    const size_t piece = std::min(kChunk, std::max(kMinPiece, ((per / 8) + 65535) & ~size_t(65535)));
     std::vector<hipError_t> status(lanes_used, hipSuccess);
     auto work = [&](int t) {
       const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, lo + per);
-      status[t] = to_device ? up(lanes[t], host, dev, lo, hi) : down(lanes[t], host, dev, lo, hi);
+      status[t] = to_device ? up(lanes[t], host, dev, lo, hi, piece) : down(lanes[t], host, dev, lo, hi, piece);
     };
     std::vector<std::thread> pool;
     for (int t = 1; t < lanes_used; ++t)

@@ -39,11 +39,11 @@ def test_pairs_and_back_to_back_calls(threads):
 
 
 @pytest.mark.gpu
-def test_strings_large_blob():
+@pytest.mark.parametrize("n", [120_000, 600_000])      # blob staged + offsets/permutation through the small path; all staged
+def test_strings_large_blob(n):
     eng = rs.Engine(0)
     eng.set_host_threads(4)
     rng = np.random.default_rng(11)
-    n = 600_000
     lens = rng.integers(0, 21, n)
     offsets = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64)
     blob = rng.integers(0, 256, int(offsets[-1]), dtype=np.uint8)      # ~6 MB blob, 4.8 MB offsets, 4.8 MB permutation

@@ -329,10 +329,12 @@ int main(int argc, char** argv) {
     else if (a == "--shapes") m.o.shapes = splitList(value());
     else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
-  {  // the first call of a thread creates its GPU context (probes, workspace); keep that out of the first timed row
-    std::vector<unsigned> warm(1 << 20);
-    for (std::size_t i = 0; i < warm.size(); ++i) warm[i] = static_cast<unsigned>(warm.size() - i);
+  {  // the first calls of a thread create its GPU context (probes, workspace) and the transfer lanes' pinned buffers;
+     // keep that out of the first timed rows
+    std::vector<unsigned> warm(8u << 20);
+    for (std::size_t i = 0; i < warm.size(); ++i) warm[i] = static_cast<unsigned>((i * 2654435761u) >> 3);
     radix_sort::sort(warm, {}, true);
+    radix_sort::sort(warm, {}, false);
   }
   const char* what = m.o.testing ? "--------TESTING STARTED--------" : "-------BENCHMARK STARTED-------";
   std::printf("%s%s\n%s\n%s\n", kRule, what, kRule, kRule);
