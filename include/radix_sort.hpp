@@ -28,6 +28,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <memory>
@@ -105,6 +106,29 @@ namespace radix_sort
 				if constexpr (std::floating_point<Key>)
 					static_assert(std::numeric_limits<Key>::is_iec559,
 						"ERROR: generators.hpp requires IEEE-754/IEC-559 compliance.\n");   // :701-707
+			}
+
+			// key::isSorted (:746-769): ascending on the projected key (IEEE keys by total order), left at the first descent.
+			// An ordered input is returned as it came -- no key column, no transfer, no gather.
+			template <typename T, typename Proj>
+			inline bool isAscending(const std::vector<T>& v, Proj& proj)
+			{
+				using Key = shared::sort_key<T, Proj>;
+				auto after = [](const Key& a, const Key& b) {
+					if constexpr (std::floating_point<Key>)
+					{
+						using U = std::conditional_t<sizeof(Key) == 4, std::uint32_t, std::uint64_t>;
+						constexpr U TOP = U(1) << (sizeof(U) * 8 - 1);
+						auto rank = [](Key x) { U u; std::memcpy(&u, &x, sizeof(U)); return (u & TOP) ? U(~u) : U(u | TOP); };
+						return rank(a) > rank(b);
+					}
+					else
+						return a > b;
+				};
+				for (std::size_t i = 0, last = v.size() - 1; i < last; i++)
+					if (after(std::invoke(proj, v[i]), std::invoke(proj, v[i + 1])))
+						return false;
+				return true;
 			}
 
 			// Host threads for the steps that stay on the CPU (key column, string packing, moving the objects): the
@@ -249,6 +273,8 @@ namespace radix_sort
 				using Key = shared::sort_key<T, Proj>;
 				const std::size_t SIZE = v.size();
 				if (SIZE < 2)
+					return;
+				if (device::isAscending(v, proj))          // :1607-1608
 					return;
 
 				if constexpr (shared::is_string<Key>)

@@ -84,6 +84,7 @@ struct rs_ctx {
   bool per_xcd_probe_ok = false;     // what the probe found
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
+  bool last_unchanged = false;   // the last sort_device found its input already in order and moved nothing
   hipEvent_t ev[kMaxPasses + 2] = {};
   int ev_count = 0;
   rst::Mover mover;        // host <-> HBM legs of the host-buffer entry points (rsort_transfer.hpp)
@@ -251,6 +252,7 @@ void launch_reverse_k(void* keys, size_t n, hipStream_t s) {
 // The device sort proper.  keys/vals are sorted in place; alt_* are same-size scratch.
 int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_vals, size_t n, int key_bytes,
                 int value_bytes, int transform, int begin_bit, int end_bit) {
+  c->last_unchanged = false;
   if (n < 2) { c->ev_count = 0; return RS_OK; }
   hipStream_t s = c->stream;
   const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
@@ -327,7 +329,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     RS_HIP(c, hipMemcpyAsync(&flags, o.flags, sizeof(flags), hipMemcpyDeviceToHost, s));
     RS_HIP(c, hipStreamSynchronize(s));
     const bool whole = begin_bit == 0 && end_bit == key_bytes * 8;
-    if ((flags & 1u) == 0) { c->ev_count = 0; return RS_OK; }
+    if ((flags & 1u) == 0) { c->ev_count = 0; c->last_unchanged = true; return RS_OK; }
     if ((flags & 2u) == 0 && whole && value_bytes == 0) {
       switch (key_bytes) {
         case 1: launch_reverse_k<uint8_t>(keys, n, s); break;
@@ -717,7 +719,7 @@ int rs_sort_keys(rs_ctx* c, void* h_keys, size_t n, int key_bytes, int transform
   if ((rc = to_device(c, d, h_keys, bytes, 0)) != RS_OK) return rc;
   if ((rc = sort_device(c, d, nullptr, d + padded, nullptr, n, key_bytes, 0, transform, begin_bit, end_bit)) != RS_OK)
     return rc;
-  if ((rc = to_host(c, h_keys, d, bytes, 0)) != RS_OK) return rc;
+  if (!c->last_unchanged && (rc = to_host(c, h_keys, d, bytes, 0)) != RS_OK) return rc;   // in order already: the caller's array is the result
   return finish_host_call(c);
 }
 
@@ -740,8 +742,10 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
   if ((rc = to_device(c, dv, h_values, vb, 1)) != RS_OK) return rc;
   if ((rc = sort_device(c, dk, dv, dk + kpad, dv + vpad, n, key_bytes, value_bytes, transform, begin_bit, end_bit)) != RS_OK)
     return rc;
-  if ((rc = to_host(c, h_keys, dk, kb, 0)) != RS_OK) return rc;
-  if ((rc = to_host(c, h_values, dv, vb, 1)) != RS_OK) return rc;
+  if (!c->last_unchanged) {                 // keys in order already: a stable sort moved neither column
+    if ((rc = to_host(c, h_keys, dk, kb, 0)) != RS_OK) return rc;
+    if ((rc = to_host(c, h_values, dv, vb, 1)) != RS_OK) return rc;
+  }
   return finish_host_call(c);
 }
 
