@@ -61,3 +61,21 @@ def test_bad_thread_count_is_an_argument_error():
     with pytest.raises(rs.RsortError):
         eng.set_host_threads(0)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_ordered_input_is_returned_without_a_download():
+    """Ascending keys: the pre-check answers, nothing is fetched back, the caller's arrays are the result (large and small
+    arrays, keys and pairs); descending keys-only input is reversed on the device and does come back."""
+    eng = rs.Engine(0)
+    eng.set_host_threads(2)
+    for n in [50_000, 3_000_000]:
+        asc = np.arange(n, dtype=np.uint32) * 3
+        assert eng.sort_keys_host(asc).tobytes() == asc.tobytes()
+        assert eng.sort_keys_host(asc[::-1].copy()).tobytes() == asc.tobytes()
+        k = (np.arange(n, dtype=np.int64) // 4)                    # ascending with ties
+        gk, gp = eng.sort_pairs_host(k)
+        assert gk.tobytes() == k.tobytes() and (gp == np.arange(n, dtype=np.uint64)).all()
+        mixed = asc.copy(); mixed[n // 2] = 0                       # one descent: a real sort, result fetched
+        assert eng.sort_keys_host(mixed).tobytes() == np.sort(mixed).tobytes()
+    eng.close()
