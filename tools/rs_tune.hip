@@ -63,8 +63,13 @@ int main(int argc, char** argv) {
   rs_ctx* c = nullptr;
   if (f_create(&c, 0)) { printf("ctx create failed\n"); return 1; }
   void *src, *work, *alt, *vals = nullptr, *valt = nullptr; unsigned* bad; unsigned long long* sums;
-  CK(hipMalloc(&src, n * kb)); CK(hipMalloc(&work, n * kb)); CK(hipMalloc(&alt, n * kb));
-  if (vb) { CK(hipMalloc(&vals, n * vb)); CK(hipMalloc(&valt, n * vb)); CK(hipMemset(vals, 0, n * vb)); }
+  // RS_TUNE_SHIFT=<bytes>: work / alt / vals / valt start 0, 1, 2, 3 shifts into their (over-sized) allocations -- does the
+  // relative placement of the ping-pong buffers matter?
+  const size_t shift = getenv("RS_TUNE_SHIFT") ? strtoull(getenv("RS_TUNE_SHIFT"), 0, 0) : 0;
+  CK(hipMalloc(&src, n * kb)); CK(hipMalloc(&work, n * kb + 4 * shift)); CK(hipMalloc(&alt, n * kb + 4 * shift));
+  alt = (char*)alt + shift;
+  if (vb) { CK(hipMalloc(&vals, n * vb + 4 * shift)); CK(hipMalloc(&valt, n * vb + 4 * shift)); vals = (char*)vals + 2 * shift; valt = (char*)valt + 3 * shift; CK(hipMemset(vals, 0, n * vb)); }
+  if (getenv("RS_TUNE_SHIFT")) printf("shift %zu: work %p alt %p vals %p valt %p\n", shift, work, alt, vals, valt);
   CK(hipMalloc(&bad, 4)); CK(hipMalloc(&sums, 16)); CK(hipMemset(bad, 0, 4)); CK(hipMemset(sums, 0, 16));
   if (kb == 4) gen<uint32_t><<<2048, 256>>>((uint32_t*)src, n, shape); else gen<uint64_t><<<2048, 256>>>((uint64_t*)src, n, shape);
   if (kb == 4) check<uint32_t><<<2048, 256>>>((uint32_t*)src, n, bad, sums); else check<uint64_t><<<2048, 256>>>((uint64_t*)src, n, bad, sums);
