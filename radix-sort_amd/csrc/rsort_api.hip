@@ -64,6 +64,7 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // where it pays -- sorts of at least this many tiles (16 M four-byte keys), which saturate the GPU on their own -- and
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
+constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) pass skipping is not worth its host synchronisation
 
 struct DevBuf {
   void* p = nullptr;
@@ -358,9 +359,14 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // Pass skipping (the device-side counterpart of getMaxLength, radix_sort.hpp:307-370, which lets the reference
   // drop high bytes that are zero): a pass whose digit is the same for every key is the identity permutation, so it
   // is not launched.  Needs the counts on the host: 2 KB per pass and one synchronisation.
+  // Short sorts of few passes do not ask: the synchronisation (about 25 us) costs more than the passes it could save
+  // (under 10 us each below kAlwaysSweepTiles tiles).
   bool live[kMaxPasses];
   int n_live = 0;
-  {
+  if (tiles <= kAlwaysSweepTiles && passes <= 4) {
+    for (int p = 0; p < passes; ++p) live[p] = true;
+    n_live = passes;
+  } else {
     unsigned long long h_hist[kMaxPasses * 256];
     RS_HIP(c, hipMemcpyAsync(h_hist, ghist, sizeof(unsigned long long) * 256 * passes, hipMemcpyDeviceToHost, s));
     RS_HIP(c, hipStreamSynchronize(s));
