@@ -78,8 +78,8 @@ struct rs_ctx {
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
   DevBuf alt_keys, alt_vals, desc, ctrl, strbuf;
-  // ctrl layout: [0, 16K) ghist  u64[8][256]; [16K, 32K) gbase u64[8][256];
-  //              [32K, 32K+64) tickets u32[16]; [32K+64, 32K+128) error flag (+pad)
+  // ctrl layout (kCtrl* below): [0, 16K) ghist u64[8][256]; [16K, 32K) gbase u64[8][256]; then per pass one ticket word
+  //              per XCD, a cache line apart (8 x kTicketWords u32); then 64 bytes: error word at +0, order-check flags at +32
   bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
   bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create (and cleared by rs_ctx_set_tile_order)
   bool per_xcd_probe_ok = false;     // what the probe found
