@@ -22,13 +22,20 @@ def main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    dev = torch.device("cuda", local_rank)
+    # RSORT_DIST_REHEARSAL=1: the same script on ONE GPU -- every rank on cuda:0, gloo instead of RCCL (the exchange is
+    # staged through host memory by dist.Comm, the bookkeeping collectives run on CPU tensors).  It rehearses this
+    # file's logic where only one GPU is at hand; its timings mean nothing.
+    rehearsal = os.environ.get("RSORT_DIST_REHEARSAL") == "1"
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if rehearsal else local_rank)
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if rehearsal:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         # The first type is the headline (same key type as the N = 1 line, so the driver's scaling ratio compares
         # like with like); the others (uint64 = BASELINE configs[4]) are reported in `rows`.
-        rows = [_run_type(args, name, rank, world, local_rank, dev) for name in args.types]
+        rows = [_run_type(args, name, rank, world, dev) for name in args.types]
         if rank == 0:
             head = rows[0]
             line = {
@@ -47,7 +54,7 @@ def main(args):
         dist.destroy_process_group()
 
 
-def _run_type(args, name, rank, world, local_rank, dev):
+def _run_type(args, name, rank, world, dev):
     import torch
     import torch.distributed as dist
 
@@ -58,7 +65,8 @@ def _run_type(args, name, rank, world, local_rank, dev):
     dt, kb, xf = shapes.KEY_TYPES[name]
     n = args.n
     sign = -(1 << 31) if kb == 4 else -(1 << 63)
-    eng = rs.Engine(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    eng = rs.Engine(dev.index, stream=torch.cuda.current_stream().cuda_stream)
+    cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")      # where the bookkeeping collectives run
     eng.set_profiling(True)
     eng.reserve(n + n // 4, kb, 0)
     local = rsd.HipLocal(eng, kb, xf)
@@ -83,24 +91,24 @@ def _run_type(args, name, rank, world, local_rank, dev):
         if it >= args.warmup:
             times.append(t1 - t0)
             pass_ms.extend(eng.profile()[1:])
-    tsum = torch.tensor([sum(times)], dtype=torch.float64, device=dev)     # max over ranks of the K timed steps
+    tsum = torch.tensor([sum(times)], dtype=torch.float64, device=cdev)     # max over ranks of the K timed steps
     dist.all_reduce(tsum, op=dist.ReduceOp.MAX)
     sec = float(tsum.item()) / len(times)
 
     # size-independent parity properties: locally sorted, rank boundaries ordered, count and checksum kept
     okey = (out ^ sign).to(torch.int64)                # unsigned order as signed
     ok_local = bool((okey[1:] >= okey[:-1]).all().item()) if out.numel() > 1 else True
-    edge = torch.stack([okey[0], okey[-1]]) if out.numel() else torch.tensor([2 ** 63 - 1, -(2 ** 63)], device=dev)
-    edges = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    edge = (torch.stack([okey[0], okey[-1]]) if out.numel() else torch.tensor([2 ** 63 - 1, -(2 ** 63)], device=dev)).to(cdev)
+    edges = torch.empty(2 * world, dtype=torch.int64, device=cdev)
     dist.all_gather_into_tensor(edges, edge)
     e = edges.cpu().view(world, 2)
     ok_edges = all(int(e[r][1]) <= int(e[r + 1][0]) for r in range(world - 1))
     stats = torch.stack([torch.tensor(out.numel(), dtype=torch.int64, device=dev), out.sum(),
                          torch.tensor(n, dtype=torch.int64, device=dev), src.sum(),
-                         torch.tensor(int(ok_local), dtype=torch.int64, device=dev)])
+                         torch.tensor(int(ok_local), dtype=torch.int64, device=dev)]).to(cdev)
     dist.all_reduce(stats)
-    sizes = torch.empty(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(sizes, torch.tensor([out.numel()], dtype=torch.int64, device=dev))
+    sizes = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([out.numel()], dtype=torch.int64, device=cdev))
     s = stats.cpu().tolist()
     total = n * world
     avg_pass = (sum(pass_ms) / len(pass_ms)) * 1e-3 if pass_ms else None

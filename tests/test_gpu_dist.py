@@ -81,3 +81,25 @@ def test_two_ranks_one_gpu_stable_pairs(tmp_path, oracle, name, shape):
     wk, wp = oracle.sort_pairs(shapes.generate(name, n, shape), xf, mt=True)
     assert gk.tobytes() == wk.tobytes()
     assert np.array_equal(gv.astype(np.uint64), wp.astype(np.uint64))
+
+
+@pytest.mark.gpu
+def test_multi_gpu_bench_script_rehearsal():
+    """bench.py --gpus 2 end to end on ONE GPU (RSORT_DIST_REHEARSAL=1: both ranks on cuda:0, gloo in place of RCCL): the
+    script the driver runs for the scaling table, its JSON line and its parity properties.  Timings are meaningless here."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSORT_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--keys", str(1 << 21)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["unit"] == "Gkeys/s" and line["scaling"] == "weak" and line["value"] > 0
+    assert [row["type"] for row in line["rows"]] == ["u32", "u64"]
+    for row in line["rows"]:
+        assert all(row["parity"].values()), row
+        assert sum(row["keys_per_rank_after_exchange"]) == 2 * (1 << 21)
