@@ -312,8 +312,10 @@ namespace radix_sort
 					if (SIZE <= std::numeric_limits<std::uint32_t>::max())
 					{
 						std::vector<std::uint32_t> indices(SIZE);   // iota (:1571-1572), 4-byte payload
-						for (std::size_t i = 0; i < SIZE; i++)
-							indices[i] = static_cast<std::uint32_t>(i);
+						device::forRanges(SIZE, threads, [&](std::size_t lo, std::size_t hi, std::size_t) {
+							for (std::size_t i = lo; i < hi; i++)
+								indices[i] = static_cast<std::uint32_t>(i);
+						});
 						device::check(ctx, rs_sort_pairs(ctx, k.data(), indices.data(), SIZE, static_cast<int>(sizeof(Key)), 4, XF, 0, BITS));
 						device::applyPermutation(v, indices, threads);
 					}
