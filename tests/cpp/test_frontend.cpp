@@ -4,18 +4,20 @@
 // differs between equal keys, so the comparison pins stability (as Employee does in the reference).
 // Build: g++ -std=c++20 -O2 -Iinclude tests/cpp/test_frontend.cpp -Lradix-sort_amd/lib -lrsort_hip
 #include <algorithm>
+#include <atomic>
 #include <bit>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "radix_sort.hpp"
 
-static int failures = 0;
-static int cases = 0;
+static std::atomic<int> failures{0};
+static std::atomic<int> cases{0};
 
 template <class U> static U flipped(U u) {           // IEEE-754 totalOrder as an unsigned image
   constexpr U S = U(1) << (sizeof(U) * 8 - 1);
@@ -111,6 +113,20 @@ int main() {
   check_key<double>("complex_double_threaded", 2100001, 1);     // shape 1 calls sort(v, proj) without the flag: serial host path
   check_key<std::string>("complex_str_threaded", 2100001, 0);
   check_value<std::string>("string_threaded", 2100001, 0);
-  std::printf("%d cases, WRONG SORTS: %d\n", cases, failures);
+  // The reference is re-entrant (no mutable globals): several caller threads sort at the same time.  Here each
+  // caller thread gets its own device context (thread_local), so their transfers and kernels overlap on the one GPU.
+  {
+    std::vector<std::thread> callers;
+    for (int t = 0; t < 4; t++)
+      callers.emplace_back([t] {
+        check_value<unsigned int>("uint_concurrent", 3000000 + 1000 * t, 0);     // staged transfers, threaded host side
+        check_key<int>("complex_i32_concurrent", 300000 + t, t % 3);
+        check_value<double>("double_concurrent", 50000 + t, 1);
+        check_key<std::string>("complex_str_concurrent", 20000 + t, 0);
+        check_value<unsigned short>("ushort_concurrent", 1000 + t, 0);           // single-workgroup kernel
+      });
+    for (auto& th : callers) th.join();
+  }
+  std::printf("%d cases, WRONG SORTS: %d\n", cases.load(), failures.load());
   return failures ? 1 : 0;
 }
