@@ -462,6 +462,16 @@ struct NoVal {};
 // 32, so the write-out, which reads aligned runs of consecutive positions, stays conflict-free.
 __device__ __forceinline__ unsigned stage_swizzle(unsigned p) { return p ^ ((p >> 6) & 31u); }
 
+// -DRS_CHECKED: every key store of every sweep kernel is range-checked and a store that would leave the array sets the
+// error word instead (RS_ERR_KERNEL).  For trying out new ranking / staging code on the GPU: a wrong rank then shows up as
+// an error status, not as a wild store and a GPU fault.  Costs about 2 % of a uint32 pass; off in the shipped build, whose
+// per-run check (below) covers everything but bugs in the kernel's own ranking.
+#ifdef RS_CHECKED
+constexpr bool kCheckedStores = true;
+#else
+constexpr bool kCheckedStores = false;
+#endif
+
 template <typename K, typename V, typename D, int BLOCK, int ITEMS>
 struct SweepSmem {
   static constexpr int WAVES = BLOCK / kWave;
@@ -752,12 +762,13 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     if (full || j < tile_count) {
       K k = stage_k[stage_swizzle(j)];
       D o = s.gofs[digit_at(k, a.shift, a.bits)] + j;
-      if constexpr (HAS_VAL) {
+      if constexpr (HAS_VAL || kCheckedStores) {
         // (always true after the per-run check above; kept because the pair kernels schedule measurably better with the
         // store under this predicate: uint32+uint32 pass 3.6-3.7 ms with it, 3.9-4.0 ms without, same results)
         const bool inside = static_cast<uint64_t>(o) < a.n;
         if (inside) kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
-        dst[i] = inside ? o : ~static_cast<D>(0);
+        if constexpr (HAS_VAL) dst[i] = inside ? o : ~static_cast<D>(0);
+        if constexpr (kCheckedStores) { if (!inside) __hip_atomic_store(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       } else {
         kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
       }
