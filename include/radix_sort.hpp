@@ -260,6 +260,22 @@ namespace radix_sort
 
 				if constexpr (shared::is_string<T>)
 				{
+					// isSortedBi (:269-305) on the host, as in the reference: ascending -> done, descending -> reversed in
+					// place; left at the first pair that rules both out.  (Numeric keys get the same check on the device.)
+					bool ascending = true, descending = true;
+					for (std::size_t i = 0, last = v.size() - 1; i < last && (ascending || descending); i++)
+					{
+						const int order = v[i].compare(v[i + 1]);
+						if (order > 0) ascending = false;
+						if (order < 0) descending = false;
+					}
+					if (ascending)
+						return;
+					if (descending)
+					{
+						std::reverse(v.begin(), v.end());
+						return;
+					}
 					std::identity id;
 					device::sortByStringKey(v, id, false, enableMultiThreading);
 				}

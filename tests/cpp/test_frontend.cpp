@@ -52,6 +52,7 @@ template <class T> static std::vector<T> make_keys(size_t n, int shape, std::mt1
     for (auto& x : v) { U u = shape == 1 ? uniq[gen() & 255] : static_cast<U>(gen()); std::memcpy(&x, &u, sizeof(T)); }
   }
   if (shape == 2) std::sort(v.begin(), v.end(), [](const T& a, const T& b) { return total_less(b, a); });   // reverse sorted
+  if (shape == 3) std::sort(v.begin(), v.end(), [](const T& a, const T& b) { return total_less(a, b); });   // sorted
   return v;
 }
 
@@ -113,6 +114,15 @@ int main() {
   check_key<double>("complex_double_threaded", 2100001, 1);     // shape 1 calls sort(v, proj) without the flag: serial host path
   check_key<std::string>("complex_str_threaded", 2100001, 0);
   check_value<std::string>("string_threaded", 2100001, 0);
+  // ordered inputs: the fast exits (device pre-check for numeric keys, host checks for strings and projected keys)
+  for (size_t n : {size_t(2), size_t(1000), size_t(100000), size_t(2100001)}) {
+    check_value<unsigned int>("uint_sorted", n, 3);
+    check_value<double>("double_sorted", n, 3);
+    check_value<std::string>("string_sorted", n, 3);
+    check_value<std::string>("string_reverse", n, 2);
+    check_key<int>("complex_i32_sorted", n, 3);        // shape 3 is odd: lambda projection, serial host path
+    check_key<std::string>("complex_str_sorted", n, 3);
+  }
   // The reference is re-entrant (no mutable globals): several caller threads sort at the same time.  Here each
   // caller thread gets its own device context (thread_local), so their transfers and kernels overlap on the one GPU.
   {
