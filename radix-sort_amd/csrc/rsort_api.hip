@@ -40,6 +40,9 @@ constexpr int kMaxPasses = 8;
 #ifndef RS_LOOKBACK
 #define RS_LOOKBACK 8
 #endif
+#ifndef RS_LOOKBACK_CHAIN   // look-back window of the chain-mode kernels (short walks: an eighth of the tiles per chain)
+#define RS_LOOKBACK_CHAIN 8
+#endif
 #ifndef RS_MIN_BLOCKS   // workgroups per CU the register allocator must leave room for
 #define RS_MIN_BLOCKS 2
 #endif
@@ -83,6 +86,7 @@ struct rs_ctx {
   bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
   bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create (and cleared by rs_ctx_set_tile_order)
   bool per_xcd_probe_ok = false;     // what the probe found
+  int cus = 256;                     // compute units of the device (persistent grids: 2 workgroups each)
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   bool last_unchanged = false;   // the last sort_device found its input already in order and moved nothing
@@ -100,6 +104,10 @@ constexpr size_t kCtrlBase = kMaxPasses * 256 * 8;
 constexpr size_t kCtrlTicket = 2 * kCtrlBase;
 constexpr size_t kCtrlError = kCtrlTicket + kMaxPasses * rsk::kTicketWords * sizeof(unsigned);   // per pass: one ticket word per XCD, a cache line apart
 constexpr size_t kCtrlBytes = kCtrlError + 64;   // error word at +0, order-check flags at +32
+// chain mode only (rsort_kernels.hpp, "XCD chains"), zeroed only by sorts that use it:
+constexpr size_t kCtrlChainHist = (kCtrlBytes + 255) & ~size_t(255);                       // u64 [8 chains][8 passes][256] from the histogram kernel
+constexpr size_t kCtrlNextCnt = kCtrlChainHist + rsk::kXcds * rsk::kChainHistStride * 8;   // u64 [8 passes][8 chains][256] from the sweeps
+constexpr size_t kCtrlBytesChain = kCtrlNextCnt + kMaxPasses * rsk::kXcds * 256 * 8;
 
 int fail(rs_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -158,11 +166,28 @@ int check_args(rs_ctx* c, const void* keys, size_t n, int key_bytes, int value_b
 }
 
 template <typename K, typename V, typename D>
-void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, hipStream_t s) {
+void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, bool chain, unsigned chain_grid, hipStream_t s) {
   constexpr int kVal = std::is_same<V, rsk::NoVal>::value ? 0 : static_cast<int>(sizeof(V));
   constexpr int kBlock = sweep_block(static_cast<int>(sizeof(K)), kVal);
   constexpr int kItems = sweep_items(static_cast<int>(sizeof(K)), kVal);
   constexpr int kMinBlocks = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
+  // (8-byte descriptors with the 16384-key tiles would need more LDS than two workgroups per CU leave: not built)
+  if constexpr (sizeof(K) >= 4 && !(sizeof(D) == 8 && narrow_geometry(static_cast<int>(sizeof(K)), kVal))) {
+    if (chain) {   // persistent workgroups, one chain of tiles per XCD (only with the returning-add ranking)
+      auto launch = [&](auto kernel) {
+        static const int per_cu = [&] {      // resident workgroups per CU (registers, LDS, wave slots)
+          int nb = 0;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 1;
+          return nb;
+        }();
+        hipLaunchKernelGGL(kernel, dim3(chain_grid * per_cu), dim3(kBlock), 0, s, a);
+      };
+      // the last launched pass has no next digit to count for
+      if (a.next_cnt) launch(rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK_CHAIN, kMinBlocks, true, true, true>);
+      else launch(rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK_CHAIN, kMinBlocks, true, true, false>);
+      return;
+    }
+  }
   if (atomic_rank)
     hipLaunchKernelGGL((rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK, kMinBlocks, true>),
                        dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0, s, a);
@@ -171,25 +196,29 @@ void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, hipSt
                        dim3(static_cast<unsigned>(tiles)), dim3(kBlock), 0, s, a);
 }
 
+struct SweepLaunch {
+  size_t tiles; int key_bytes; int value_bytes; bool wide; bool atomic_rank; bool chain; unsigned chain_grid /* compute units */; hipStream_t s;
+};
+
 template <typename K, typename V>
-void launch_sweep_d(const rsk::SweepArgs& a, size_t tiles, bool wide, bool ar, hipStream_t s) {
-  if (wide) launch_sweep<K, V, uint64_t>(a, tiles, ar, s);
-  else launch_sweep<K, V, uint32_t>(a, tiles, ar, s);
+void launch_sweep_d(const rsk::SweepArgs& a, const SweepLaunch& l) {
+  if (l.wide) launch_sweep<K, V, uint64_t>(a, l.tiles, l.atomic_rank, l.chain, l.chain_grid, l.s);
+  else launch_sweep<K, V, uint32_t>(a, l.tiles, l.atomic_rank, l.chain, l.chain_grid, l.s);
 }
 
 template <typename K>
-void launch_sweep_v(const rsk::SweepArgs& a, size_t tiles, int value_bytes, bool wide, bool ar, hipStream_t s) {
-  if (value_bytes == 0) launch_sweep_d<K, rsk::NoVal>(a, tiles, wide, ar, s);
-  else if (value_bytes == 4) launch_sweep_d<K, uint32_t>(a, tiles, wide, ar, s);
-  else launch_sweep_d<K, uint64_t>(a, tiles, wide, ar, s);
+void launch_sweep_v(const rsk::SweepArgs& a, const SweepLaunch& l) {
+  if (l.value_bytes == 0) launch_sweep_d<K, rsk::NoVal>(a, l);
+  else if (l.value_bytes == 4) launch_sweep_d<K, uint32_t>(a, l);
+  else launch_sweep_d<K, uint64_t>(a, l);
 }
 
-void launch_sweep_k(const rsk::SweepArgs& a, size_t tiles, int key_bytes, int value_bytes, bool wide, bool ar, hipStream_t s) {
-  switch (key_bytes) {
-    case 1: launch_sweep_v<uint8_t>(a, tiles, value_bytes, wide, ar, s); break;
-    case 2: launch_sweep_v<uint16_t>(a, tiles, value_bytes, wide, ar, s); break;
-    case 4: launch_sweep_v<uint32_t>(a, tiles, value_bytes, wide, ar, s); break;
-    default: launch_sweep_v<uint64_t>(a, tiles, value_bytes, wide, ar, s); break;
+void launch_sweep_k(const rsk::SweepArgs& a, const SweepLaunch& l) {
+  switch (l.key_bytes) {
+    case 1: launch_sweep_v<uint8_t>(a, l); break;
+    case 2: launch_sweep_v<uint16_t>(a, l); break;
+    case 4: launch_sweep_v<uint32_t>(a, l); break;
+    default: launch_sweep_v<uint64_t>(a, l); break;
   }
 }
 
@@ -287,7 +316,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   }
 
   int rc;
-  if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
+  if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
   if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
   if (!alt_keys) {
     if ((rc = ensure(c, c->alt_keys, n * key_bytes)) != RS_OK) return rc;
@@ -344,16 +373,46 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     }
   }
 
+  // Chain mode (rsort_kernels.hpp, "XCD chains"): one chain of tiles per XCD, swept by persistent workgroups.  For sorts
+  // large enough to keep every XCD busy with its own chain, on devices where the XCC-id probe found all eight XCDs, with
+  // the returning-add ranking, 4- and 8-byte keys, 16-byte aligned keys (the histogram kernel counts per chain in packs).
+  static const long chain_min_tiles = [] { const char* e = std::getenv("RSORT_CHAIN_MIN_TILES"); return e ? std::atol(e) : 4096l; }();
+  static const bool chain_env = [] { const char* e = std::getenv("RSORT_CHAIN"); return !(e && e[0] == '0'); }();
+  const bool chain = chain_env && c->per_xcd_order && c->rank_by_lds_atomic && key_bytes >= 4 &&
+                     static_cast<long>(tiles) >= chain_min_tiles && (reinterpret_cast<uintptr_t>(keys) & 15u) == 0 &&
+                     n < (size_t(1) << 35) && !(wide && narrow_geometry(key_bytes, value_bytes));
+  unsigned chain_tiles = 0, chunk_shift = 0, chunk_mul = 0;
+  if (chain) {
+    // chains of U8 << r tiles, r such that positions >> (log2(tile) + r) stay below 256: the chain of an output position is
+    // then one shift, one 24-bit multiply and one shift (checked here for every value the kernel can meet)
+    unsigned r = 0;
+    while (((tiles + (size_t(1) << r) - 1) >> r) > 255) ++r;
+    const unsigned u_max = static_cast<unsigned>((tiles + (size_t(1) << r) - 1) >> r);
+    const unsigned u8 = (u_max + rsk::kXcds - 1) / rsk::kXcds;
+    chain_tiles = u8 << r;
+    unsigned tile_log2 = 0;
+    while ((size_t(1) << tile_log2) < tile_keys(key_bytes, value_bytes)) ++tile_log2;
+    chunk_shift = tile_log2 + r;
+    chunk_mul = (65536u + u8 - 1) / u8;
+    for (unsigned u = 0; u < u_max; ++u)
+      if (((u * chunk_mul) >> 16) != u / u8 || u / u8 >= rsk::kXcds) return fail(c, RS_ERR_KERNEL, "chain split arithmetic");
+  }
+
   int ev = 0;
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
-  RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlBytes, s));
+  RS_HIP(c, hipMemsetAsync(ctrl, 0, chain ? kCtrlBytesChain : kCtrlBytes, s));
   RS_HIP(c, hipMemsetAsync(c->desc.p, 0, tiles * 256 * (wide ? 8 : 4), s));   // the rows this sort uses, not the whole reservation
 
+  auto* chain_hist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlChainHist);
+  auto* next_cnt = reinterpret_cast<unsigned long long*>(ctrl + kCtrlNextCnt);
   rsk::HistArgs h{};
   h.keys = keys; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
   h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
-  launch_hist(h, key_bytes, hist_grid(n, key_bytes), s);
-  hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase);
+  h.chain_hist = chain ? chain_hist : nullptr;
+  h.chain_keys = chain ? static_cast<uint64_t>(chain_tiles) * tile_keys(key_bytes, value_bytes) : 0;
+  launch_hist(h, key_bytes, chain ? 256u * (key_bytes == 8 ? 1 : 2) : hist_grid(n, key_bytes), s);
+  hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase,
+                     static_cast<const unsigned long long*>(chain ? chain_hist : nullptr));
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
 
   // Pass skipping (the device-side counterpart of getMaxLength, radix_sort.hpp:307-370, which lets the reference
@@ -361,28 +420,27 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // is not launched.  Needs the counts on the host: 2 KB per pass and one synchronisation.
   // Short sorts of few passes do not ask: the synchronisation (about 25 us) costs more than the passes it could save
   // (under 10 us each below kAlwaysSweepTiles tiles).
-  bool live[kMaxPasses];
+  int live[kMaxPasses];     // the passes that are launched, in order
   int n_live = 0;
   if (tiles <= kAlwaysSweepTiles && passes <= 4) {
-    for (int p = 0; p < passes; ++p) live[p] = true;
-    n_live = passes;
+    for (int p = 0; p < passes; ++p) live[n_live++] = p;
   } else {
     unsigned long long h_hist[kMaxPasses * 256];
     RS_HIP(c, hipMemcpyAsync(h_hist, ghist, sizeof(unsigned long long) * 256 * passes, hipMemcpyDeviceToHost, s));
     RS_HIP(c, hipStreamSynchronize(s));
     for (int p = 0; p < passes; ++p) {
-      live[p] = true;
+      bool constant = false;
       for (int d = 0; d < 256; ++d)
-        if (h_hist[p * 256 + d] == n) { live[p] = false; break; }
-      n_live += live[p];
+        if (h_hist[p * 256 + d] == n) { constant = true; break; }
+      if (!constant) live[n_live++] = p;
     }
   }
 
   void* kin = keys; void* kout = alt_keys;
   void* vin = vals; void* vout = alt_vals;
-  int done = 0;
-  for (int p = 0; p < passes; ++p) {
-    if (!live[p]) continue;
+  const SweepLaunch launch{tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, chain, static_cast<unsigned>(c->cus), s};
+  for (int done = 0; done < n_live; ++done) {
+    const int p = live[done];
     rsk::SweepArgs a{};
     a.keys_in = kin; a.keys_out = kout; a.vals_in = vin; a.vals_out = vout;
     a.desc = c->desc.p; a.ticket = tickets + p * rsk::kTicketWords; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
@@ -393,11 +451,22 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
     a.per_xcd_order = c->per_xcd_order && tiles >= kPerXcdMinTiles ? 1 : 0;
     a.incl_code = 2u + (done & 1);          // alternates over the LAUNCHED passes (descriptor parity, rsort_kernels.hpp)
-    launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, s);
+    if (chain) {
+      // this pass' digit counts per chain: from the histogram kernel for the first launched pass, from the previous sweep after that
+      a.chain_cnt = done == 0 ? chain_hist + p * rsk::kRadix : next_cnt + static_cast<size_t>(done - 1) * rsk::kXcds * rsk::kRadix;
+      a.chain_cnt_stride = done == 0 ? rsk::kChainHistStride : rsk::kRadix;
+      a.chain_tiles = chain_tiles;
+      a.chunk_shift = chunk_shift; a.chunk_mul = chunk_mul;
+      if (done + 1 < n_live) {
+        a.next_cnt = next_cnt + static_cast<size_t>(done) * rsk::kXcds * rsk::kRadix;
+        a.next_shift = begin_bit + live[done + 1] * rsk::kRadixBits;
+        a.next_bits = std::min(rsk::kRadixBits, end_bit - a.next_shift);
+      }
+    }
+    launch_sweep_k(a, launch);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     std::swap(kin, kout);
     std::swap(vin, vout);
-    ++done;
   }
   RS_HIP(c, hipGetLastError());
   if (n_live & 1) {   // result sits in the alternate buffers
@@ -510,6 +579,10 @@ int rs_ctx_create(rs_ctx** out, int device) {
     return RS_ERR_HIP;
   }
   c->stream = c->own_stream;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
+  }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { rs_ctx_destroy(c); return RS_ERR_HIP; }
   // Ranking shortcut: usable only if returning LDS adds of one wave instruction are served in lane order.
@@ -582,7 +655,7 @@ int rs_ctx_reserve(rs_ctx* c, size_t n, int key_bytes, int value_bytes) {
   int rc = check_args(c, reinterpret_cast<void*>(1), n, key_bytes, value_bytes, RS_XF_NONE, 0, key_bytes * 8);
   if (rc != RS_OK) return rc;
   RS_HIP(c, hipSetDevice(c->device));
-  if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
+  if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
   if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
   if ((rc = ensure(c, c->alt_keys, n * key_bytes)) != RS_OK) return rc;
   if (value_bytes && (rc = ensure(c, c->alt_vals, n * value_bytes)) != RS_OK) return rc;
@@ -666,7 +739,7 @@ int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, cons
   static const bool force_wide = [] { const char* e = std::getenv("RSORT_FORCE_WIDE"); return e && e[0] == '1'; }();
   const bool wide = n > kSmallDescLimit || force_wide;
   if (tiles > 0x7FFFFFFFull) return fail(c, RS_ERR_ARG, "n too large for one launch");
-  if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
+  if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
   if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
   char* ctrl = static_cast<char*>(c->ctrl.p);
   auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);
@@ -684,7 +757,7 @@ int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, cons
   h.keys = d_keys_in; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
   h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = 1;
   launch_hist(h, key_bytes, hist_grid(n, key_bytes), s);
-  hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(1), dim3(rsk::kRadix), 0, s, ghist, gbase);
+  hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(1), dim3(rsk::kRadix), 0, s, ghist, gbase, static_cast<const unsigned long long*>(nullptr));
   unsigned long long counts[256];
   RS_HIP(c, hipMemcpyAsync(counts, ghist, sizeof(counts), hipMemcpyDeviceToHost, s));
   RS_HIP(c, hipStreamSynchronize(s));
@@ -706,7 +779,7 @@ int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, cons
   a.shift = begin_bit; a.bits = end_bit - begin_bit;
   a.per_xcd_order = c->per_xcd_order && tiles >= kPerXcdMinTiles ? 1 : 0;
   a.incl_code = 2u;
-  launch_sweep_k(a, tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, s);
+  launch_sweep_k(a, SweepLaunch{tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, false, 0, s});
   RS_HIP(c, hipGetLastError());
   return RS_OK;
 }
@@ -765,7 +838,7 @@ int rs_digit_histogram_device(rs_ctx* c, const void* d_keys, size_t n, int key_b
   std::memset(h_counts, 0, sizeof(uint64_t) * 256 * passes);
   if (n == 0) return RS_OK;
   RS_HIP(c, hipSetDevice(c->device));
-  if ((rc = ensure(c, c->ctrl, kCtrlBytes)) != RS_OK) return rc;
+  if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
   hipStream_t s = c->stream;
   char* ctrl = static_cast<char*>(c->ctrl.p);
   auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);

@@ -39,7 +39,7 @@
 __device__ unsigned long long rs_stamp_buf[16 * 4096];
 #define RS_STAMP(slot)                                                                        \
   do {                                                                                        \
-    if (tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096)                                   \
+    if (RS_STAMP_ON && tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096)                    \
       rs_stamp_buf[(slot) * 4096 + (tile >> 6)] = wall_clock64();                             \
   } while (0)
 #else
@@ -197,7 +197,13 @@ struct HistArgs {
   int begin_bit;
   int end_bit;
   int passes;
+  // chain mode (see "XCD chains" at the sweep kernel): workgroup b counts inside chain (b & 7)'s key range
+  // [chain * chain_keys, (chain + 1) * chain_keys) and adds to chain_hist[chain][pass][digit] (rows of kChainHistStride);
+  // chain_keys == 0: one range, counts go to ghist.  Needs 16-byte aligned keys and chain_keys % (16 / sizeof(K)) == 0.
+  unsigned long long* chain_hist;
+  uint64_t chain_keys;
 };
+constexpr unsigned kChainHistStride = 8 * 256;   // words between two chains' tables in chain_hist
 
 // LDS layout of the per-workgroup histogram: [pass][digit][kHistCols] 32-bit counters, a lane adds
 // to column (lane & 15).  The 32 lanes the LDS serves together then touch 16 different banks with
@@ -237,15 +243,24 @@ __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
 
   const K* keys = static_cast<const K*>(a.keys);
   const K fm = static_cast<K>(a.fmask), sm = static_cast<K>(a.smask);
+  // the key range [lo, hi) this workgroup counts in, as worker `wb` of `nwb`
+  const bool chained = a.chain_keys != 0;
+  const unsigned chain = chained ? blockIdx.x & 7u : 0u;
+  const uint64_t wb = chained ? blockIdx.x >> 3 : blockIdx.x, nwb = chained ? gridDim.x >> 3 : gridDim.x;
+  uint64_t lo = 0, hi = a.n;
+  if (chained) {
+    lo = chain * a.chain_keys < a.n ? chain * a.chain_keys : a.n;
+    hi = lo + a.chain_keys < a.n ? lo + a.chain_keys : a.n;
+  }
   // head: keys before the first 16-byte boundary (the multi-GPU splitter passes sub-range pointers that are only
-  // key-aligned); tail: what is left after the last whole 16-byte pack
-  uint64_t head = ((16u - (reinterpret_cast<uintptr_t>(keys) & 15u)) & 15u) / sizeof(K);
+  // key-aligned; never in chain mode); tail: what is left after the last whole 16-byte pack
+  uint64_t head = chained ? 0 : ((16u - (reinterpret_cast<uintptr_t>(keys) & 15u)) & 15u) / sizeof(K);
   if (head > a.n) head = a.n;
-  const uint64_t nvec = (a.n - head) / VEC;
+  const uint64_t vlo = chained ? lo / VEC : 0, nvec = chained ? hi / VEC : (a.n - head) / VEC;   // packs [vlo, nvec)
   struct alignas(16) Pack { K v[VEC]; };
   const Pack* vkeys = reinterpret_cast<const Pack*>(keys + head);
-  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * BLOCK;
-  uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + threadIdx.x;
+  const uint64_t stride = nwb * BLOCK;
+  uint64_t i = vlo + wb * BLOCK + threadIdx.x;
   for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
     Pack pk[UNROLL];
 #pragma unroll
@@ -260,17 +275,18 @@ __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(pk.v[j], fm, sm), col, a);
   }
-  if (blockIdx.x == 0) {                          // fewer than 2 * VEC keys
+  if (wb == 0 && (!chained || (hi == a.n && lo < hi))) {   // fewer than 2 * VEC keys: head, and the tail after the last pack
     if (threadIdx.x < head) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(keys[threadIdx.x], fm, sm), col, a);
     uint64_t t = head + nvec * VEC + threadIdx.x;
     if (t < a.n) hist_add_key<K, MAX_PASSES, WHOLE>(xf_forward(keys[t], fm, sm), col, a);
   }
   __syncthreads();
+  unsigned long long* dst = chained ? a.chain_hist + static_cast<size_t>(chain) * kChainHistStride : a.ghist;
   for (int b = threadIdx.x; b < a.passes * kRadix; b += BLOCK) {
     unsigned c = 0;
 #pragma unroll
     for (int j = 0; j < kHistCols; ++j) c += lh[b * kHistCols + ((j + b) & (kHistCols - 1))];
-    if (c) atomicAdd(&a.ghist[b], static_cast<unsigned long long>(c));
+    if (c) atomicAdd(&dst[b], static_cast<unsigned long long>(c));
   }
 }
 
@@ -287,11 +303,19 @@ __device__ __forceinline__ unsigned long long wave_inclusive_scan(unsigned long 
   return v;
 }
 
-__global__ __launch_bounds__(kRadix) void digit_scan_kernel(const unsigned long long* ghist,
-                                                           unsigned long long* gbase) {
+// chain_hist != null: the counts arrive per chain (HistArgs::chain_hist); their sums are written to ghist first
+__global__ __launch_bounds__(kRadix) void digit_scan_kernel(unsigned long long* ghist, unsigned long long* gbase,
+                                                           const unsigned long long* chain_hist) {
   __shared__ unsigned long long wsum[kRadix / kWave];
   const int p = blockIdx.x, d = threadIdx.x;
-  unsigned long long c = ghist[p * kRadix + d];
+  unsigned long long c;
+  if (chain_hist) {
+    c = 0;
+    for (unsigned x = 0; x < 8; ++x) c += chain_hist[x * kChainHistStride + p * kRadix + d];
+    ghist[p * kRadix + d] = c;
+  } else {
+    c = ghist[p * kRadix + d];
+  }
   unsigned long long inc = wave_inclusive_scan(c);
   if ((d & (kWave - 1)) == kWave - 1) wsum[d / kWave] = inc;
   __syncthreads();
@@ -386,6 +410,14 @@ struct SweepArgs {
   int bits;
   unsigned incl_code;               // 2 + (pass & 1)
   int per_xcd_order;                // tiles from one ticket counter per XCD (rs_ctx_create probes whether that is safe)
+  // chain mode only (CHAIN kernels, see "XCD chains" below)
+  const unsigned long long* chain_cnt;   // [kXcds] rows of 256: this pass' digit counts over each chain's input range
+  unsigned chain_cnt_stride;             // words between two rows of chain_cnt
+  unsigned chain_tiles;                  // tiles per chain (the last chain may hold fewer)
+  unsigned long long* next_cnt;          // [kXcds][256] counts of the NEXT launched pass' digit over each chain's range of this
+                                         // pass' output (accumulated here); null in the last pass
+  int next_shift, next_bits;             // the next launched pass' digit
+  unsigned chunk_shift, chunk_mul;       // chain of output position o = (mul_u24(o >> chunk_shift, chunk_mul)) >> 16
 };
 
 // Lanes of the wave whose digit DIFFERS from this lane's, as two 32-bit halves: per bit, the
@@ -404,9 +436,13 @@ __device__ __forceinline__ void differ_mask(unsigned d, unsigned& lo, unsigned& 
 template <typename D> __device__ __forceinline__ D desc_load(const D* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <typename D> __device__ __forceinline__ void desc_store(D* p, D v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// LOCAL: every reader runs on the writer's XCD (chain mode) -- a store that stays in that XCD's L2 (no write-through)
+template <bool LOCAL = false, typename D> __device__ __forceinline__ void desc_store(D* p, D v) {
+  if constexpr (LOCAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+template <bool C, typename A, typename B> struct Pick { using type = A; };
+template <typename A, typename B> struct Pick<false, A, B> { using type = B; };
 
 // Bounded wait helper: call once per unsuccessful poll; true = give up (timeout, or another
 // workgroup already reported a fault).  ~2 s of wall clock (s_memrealtime ticks at 100 MHz).
@@ -490,7 +526,32 @@ struct SweepSmem {
   unsigned out_of_range;            // some digit's run of this tile would end past the array (see the write-out)
 };
 
-template <typename K, typename V, typename D, int BLOCK, int ITEMS, int LOOKBACK = 8, int MIN_BLOCKS = 1, bool RANK_BY_LDS_ATOMIC = true>
+// XCD chains (CHAIN kernels).  The tiles of a pass are cut into kXcds contiguous ranges ("chains") and chain x is swept
+// by the workgroups that run on XCD x, front to back, each with its own ticket counter and its own chained scan:
+//   * a tile only ever waits for tiles of its own chain, all of which run on the same XCD, so the look-back
+//     descriptors never leave that XCD's L2: they are published with plain stores (the line stays in L2) and polled
+//     with L1-bypassing loads that L2 serves -- a few hundred cycles per round trip instead of the 1.5 us of a
+//     write-through store plus a fabric read under load, and walks of a few rows instead of 24, because only an
+//     eighth of the chip's tiles are queued on each chain;
+//   * the runs that consecutive tiles write for one digit are adjacent; with all of a chain on one XCD every
+//     partial line at a run boundary is completed in one L2 before it is written back;
+//   * where chain x's output starts inside each digit's run needs this pass' digit counts over every chain's
+//     input range.  For the first launched pass they come from the histogram kernel (each of its workgroups
+//     counts inside one chain's range); for later passes the previous sweep counts them: in its write-out every
+//     key adds to an LDS table (chain of its output position, next digit), summed in registers over the
+//     workgroup's tiles and added to global memory once at the end.
+// Workgroups are persistent (2 per CU) and take the chain of the XCD they find themselves on (XCC_ID), so the
+// placement the dispatcher chooses does not matter for correctness as long as every XCD gets a workgroup, which
+// rs_ctx_create probes.
+template <typename D, bool COUNT>
+struct ChainSmem {
+  // 16-bit cells [chain >> 1][next digit][chain & 1], two to a word: cell counts of ONE tile (< 65536)
+  unsigned ccnt[COUNT ? kXcds / 2 * kRadix : 1];
+  D cbase[kRadix];                  // where this chain's output starts inside each digit's run
+};
+struct NoChainSmem {};
+
+template <typename K, typename V, typename D, int BLOCK, int ITEMS, int LOOKBACK = 8, int MIN_BLOCKS = 1, bool RANK_BY_LDS_ATOMIC = true, bool CHAIN = false, bool COUNT = false>
 __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesweep_kernel(SweepArgs a) {
   using Smem = SweepSmem<K, V, D, BLOCK, ITEMS>;
   constexpr int WAVES = Smem::WAVES;
@@ -498,8 +559,46 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   constexpr bool HAS_VAL = Smem::HAS_VAL;
   static_assert(BLOCK >= kRadix, "one thread per digit");
   __shared__ Smem s;
+  __shared__ typename Pick<CHAIN, ChainSmem<D, COUNT>, NoChainSmem>::type cs;
 
-  const unsigned tid = threadIdx.x;
+  const unsigned tid0 = threadIdx.x;
+  const unsigned tiles_total = static_cast<unsigned>((a.n + TILE - 1) / TILE);
+
+  // chain mode: this workgroup's chain is the XCD it runs on; it sweeps tiles of that chain until none is left
+  constexpr int CW = CHAIN ? (kXcds / 2 * kRadix + BLOCK - 1) / BLOCK : 1;   // words of cs.ccnt per thread
+  unsigned chain = 0, chain_first = 0, chain_end = 0;
+  unsigned acc[2 * CW];                    // (chain of the output position, next digit) counts over this workgroup's tiles
+  static_assert(CHAIN || !COUNT, "only chain-mode kernels count for the next pass");
+#ifdef RS_STAMPS
+#ifdef RS_STAMP_COUNT_PASSES     // stamps from the counting passes only (the last pass would overwrite them)
+  constexpr bool RS_STAMP_ON = COUNT;
+#else
+  constexpr bool RS_STAMP_ON = true;
+#endif
+#endif
+  if constexpr (CHAIN) {
+    chain = xcc_id();
+    const unsigned long long first = static_cast<unsigned long long>(chain) * a.chain_tiles;
+    chain_first = first < tiles_total ? static_cast<unsigned>(first) : tiles_total;
+    chain_end = first + a.chain_tiles < tiles_total ? static_cast<unsigned>(first + a.chain_tiles) : tiles_total;
+    if (tid0 < kRadix) {
+      unsigned long long cbase = a.gbase[tid0];
+      for (unsigned c = 0; c < chain; ++c) cbase += a.chain_cnt[static_cast<size_t>(c) * a.chain_cnt_stride + tid0];
+      cs.cbase[tid0] = static_cast<D>(cbase);
+    }
+#pragma unroll
+    for (int e = 0; e < CW; ++e) {
+      acc[2 * e] = acc[2 * e + 1] = 0;
+      if (COUNT && tid0 + e * BLOCK < kXcds / 2 * kRadix) cs.ccnt[tid0 + e * BLOCK] = 0;
+    }
+  }
+
+  for (;;) {   // one tile per trip; kernels without CHAIN leave after the first
+  // In the persistent (CHAIN) form everything derived from the thread id is loop-invariant, and the compiler would keep
+  // all of it (addresses, segment offsets) in registers across the whole tile: the id is passed through an empty asm
+  // so that each trip derives what it needs where it needs it, as the one-tile kernel does.
+  unsigned tid = tid0;
+  if constexpr (CHAIN) asm volatile("" : "+v"(tid));
   const unsigned lane = tid & (kWave - 1);
   const unsigned wave = tid / kWave;
 
@@ -507,17 +606,23 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   unsigned long long stamp_begin = wall_clock64();
 #endif
   if (tid == 0) {
-    s.tile_id = draw_tile(a.ticket, static_cast<unsigned>((a.n + TILE - 1) / TILE), a.per_xcd_order != 0);
+    if constexpr (CHAIN) {
+      const unsigned k = atomicAdd(&a.ticket[chain * 32], 1u);
+      s.tile_id = k < chain_end - chain_first ? chain_first + k : kNoTile;
+    } else {
+      s.tile_id = draw_tile(a.ticket, tiles_total, a.per_xcd_order != 0);
+    }
     s.out_of_range = 0;
   }
 #pragma unroll
   for (int i = 0; i < kRadix / 2 / kWave; ++i) reinterpret_cast<unsigned*>(s.whist[wave])[i * kWave + lane] = 0;
   __syncthreads();
 
-  if (s.tile_id == kNoTile) return;               // workgroup-uniform; cannot happen with one workgroup per tile
+  if (s.tile_id == kNoTile) break;                // workgroup-uniform; without CHAIN it cannot happen (one workgroup per tile)
   const uint64_t tile = s.tile_id;
+  const uint64_t first_tile = CHAIN ? chain_first : 0u;   // the tile whose aggregate is its inclusive prefix
 #ifdef RS_STAMPS
-  if (tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096) rs_stamp_buf[tile >> 6] = stamp_begin;
+  if (RS_STAMP_ON && tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096) rs_stamp_buf[tile >> 6] = stamp_begin;
 #endif
   RS_STAMP(1);
   const uint64_t tile_base = tile * TILE;
@@ -650,8 +755,8 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) sum += s.whist[w][tid];
     my_count = sum;
-    D word = (static_cast<D>(tile == 0 ? a.incl_code : kCodeAgg) << Desc<D>::kShift) | static_cast<D>(sum);
-    desc_store(&desc[tile * kRadix + tid], word);
+    D word = (static_cast<D>(tile == first_tile ? a.incl_code : kCodeAgg) << Desc<D>::kShift) | static_cast<D>(sum);
+    desc_store<CHAIN>(&desc[tile * kRadix + tid], word);
     unsigned v = sum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -691,7 +796,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   // ---- decoupled look-back: one thread per digit, LOOKBACK predecessors per round trip --------------
   if (tid < kRadix) {
     unsigned long long excl = 0;
-    if (tile > 0) {
+    if (tile > first_tile) {
       long long t = static_cast<long long>(tile) - 1;     // next predecessor to consume
       SpinGuard guard;
       bool failed = false;
@@ -706,7 +811,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
         for (int j = 0; j < LOOKBACK; ++j) {
           long long tt = t - j;
-          w[j] = desc_load(&desc[static_cast<uint64_t>(tt < 0 ? 0 : tt) * kRadix + tid]);
+          w[j] = desc_load(&desc[static_cast<uint64_t>(tt < static_cast<long long>(first_tile) ? first_tile : tt) * kRadix + tid]);
         }
         bool done = false;
         int consumed = 0;
@@ -726,7 +831,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
         if (consumed == 0 && guard.expired(a.error_flag)) { failed = true; break; }
       }
 #ifdef RS_STAMPS
-      if (tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096) {
+      if (RS_STAMP_ON && tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096) {
         rs_stamp_buf[8 * 4096 + (tile >> 6)] = trips;
         rs_stamp_buf[9 * 4096 + (tile >> 6)] = empty_trips;
         rs_stamp_buf[10 * 4096 + (tile >> 6)] = static_cast<unsigned long long>(static_cast<long long>(tile) - 1 - t);
@@ -735,9 +840,10 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
       if (failed) __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       D word = (static_cast<D>(a.incl_code) << Desc<D>::kShift) |
                (static_cast<D>(excl + my_count) & Desc<D>::kValueMask);
-      desc_store(&desc[tile * kRadix + tid], word);
+      desc_store<CHAIN>(&desc[tile * kRadix + tid], word);
     }
-    const unsigned long long run_begin = a.gbase[tid] + excl;
+    unsigned long long run_begin = excl;
+    if constexpr (CHAIN) run_begin += cs.cbase[tid]; else run_begin += a.gbase[tid];
     s.gofs[tid] = static_cast<D>(run_begin - s.tile_start[tid]);
     // Offsets come from the up-front histogram; keys that change while the sort runs (a caller that did not wait for
     // whatever produces them) make the two disagree.  A tile with a run that would end past the array reports that
@@ -748,7 +854,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   RS_STAMP(6);
   if (s.out_of_range) {                            // workgroup-uniform
     if (tid == 0) __hip_atomic_store(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
+    break;
   }
 
   // ---- write out: consecutive threads write consecutive addresses inside each digit run -------------
@@ -762,6 +868,15 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     if (full || j < tile_count) {
       K k = stage_k[stage_swizzle(j)];
       D o = s.gofs[digit_at(k, a.shift, a.bits)] + j;
+      if constexpr (CHAIN) {
+        if constexpr (COUNT) {
+          // (chain of the output position, next digit) -> one 16-bit cell; straight-line code on purpose: a branch here
+          // (even a wave-uniform one) keeps the compiler from overlapping the sixteen rounds' LDS reads and stores
+          const unsigned dn = digit_at(k, a.next_shift, a.next_bits);
+          const unsigned c = __umul24(static_cast<unsigned>(o >> a.chunk_shift), a.chunk_mul) >> 16;
+          atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], 1u << ((c & 1u) << 4));
+        }
+      }
       if constexpr (HAS_VAL || kCheckedStores) {
         // (always true after the per-run check above; kept because the pair kernels schedule measurably better with the
         // store under this predicate: uint32+uint32 pass 3.6-3.7 ms with it, 3.9-4.0 ms without, same results)
@@ -798,6 +913,39 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     for (int i = 0; i < ITEMS; ++i) {
       unsigned j = i * BLOCK + tid;
       if ((full || j < tile_count) && dst[i] != ~static_cast<D>(0)) vout[dst[i]] = stage_v[j];
+    }
+  }
+
+  if constexpr (!CHAIN) break;
+  else {
+    // fold this tile's (chain, next digit) cells into the registers and clear them for the next tile
+    __syncthreads();
+    if constexpr (COUNT) {
+#pragma unroll
+      for (int e = 0; e < CW; ++e) {
+        const unsigned wi = tid + e * BLOCK;
+        if (wi < kXcds / 2 * kRadix) {
+          const unsigned w = cs.ccnt[wi];
+          cs.ccnt[wi] = 0;
+          acc[2 * e] += w & 0xFFFFu;
+          acc[2 * e + 1] += w >> 16;
+        }
+      }
+    }
+  }
+  }   // tile loop
+
+  if constexpr (CHAIN) {
+    if constexpr (COUNT) {
+#pragma unroll
+      for (int e = 0; e < CW; ++e) {
+        const unsigned wi = tid0 + e * BLOCK;
+        if (wi < kXcds / 2 * kRadix) {
+          const unsigned c2 = wi >> 8, dn = wi & (kRadix - 1);
+          if (acc[2 * e]) atomicAdd(&a.next_cnt[(2 * c2) * kRadix + dn], static_cast<unsigned long long>(acc[2 * e]));
+          if (acc[2 * e + 1]) atomicAdd(&a.next_cnt[(2 * c2 + 1) * kRadix + dn], static_cast<unsigned long long>(acc[2 * e + 1]));
+        }
+      }
     }
   }
 }
