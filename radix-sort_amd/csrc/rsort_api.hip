@@ -41,7 +41,17 @@ constexpr int kMaxPasses = 8;
 #define RS_LOOKBACK 8
 #endif
 #ifndef RS_LOOKBACK_CHAIN   // look-back window of the chain-mode kernels (short walks: an eighth of the tiles per chain)
-#define RS_LOOKBACK_CHAIN 8
+#define RS_LOOKBACK_CHAIN 4
+#endif
+// Chain-mode geometry for narrow keys: 512 threads x 16 keys = 8192-key tiles, three workgroups per CU.  With the look-back
+// inside one XCD's L2 the walk no longer argues for large tiles, and 24 waves per CU leave 80 registers per lane: the
+// counting kernels (next-pass digit counts in the write-out) then need no scratch, whose loads and stores were a fifth of
+// the 1024 x 16 kernel's vector-memory instructions (uint32 N = 2^30, pass with counting: 2.28 ms at 1024 x 16, 2.11 here).
+#ifndef RS_CHAIN_BLOCK
+#define RS_CHAIN_BLOCK 512
+#endif
+#ifndef RS_CHAIN_MIN_BLOCKS
+#define RS_CHAIN_MIN_BLOCKS 3
 #endif
 #ifndef RS_MIN_BLOCKS   // workgroups per CU the register allocator must leave room for
 #define RS_MIN_BLOCKS 2
@@ -56,8 +66,8 @@ constexpr int sweep_items(int key_bytes, int value_bytes) {
   return (key_bytes <= 4 && value_bytes <= 4) ? RS_SWEEP_ITEMS : RS_SWEEP_ITEMS_WIDE;
 }
 constexpr bool narrow_geometry(int key_bytes, int value_bytes) { return key_bytes <= 4 && value_bytes <= 4; }
-constexpr int sweep_block(int key_bytes, int value_bytes) {
-  return narrow_geometry(key_bytes, value_bytes) ? RS_SWEEP_BLOCK : RS_SWEEP_BLOCK_WIDE;
+constexpr int sweep_block(int key_bytes, int value_bytes, bool chain = false) {
+  return narrow_geometry(key_bytes, value_bytes) ? (chain ? RS_CHAIN_BLOCK : RS_SWEEP_BLOCK) : RS_SWEEP_BLOCK_WIDE;
 }
 constexpr int kHistBlock = 1024;
 constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-byte descriptor
@@ -138,11 +148,11 @@ int ensure(rs_ctx* c, DevBuf& b, size_t bytes) {
   return RS_OK;
 }
 
-size_t tile_keys(int key_bytes, int value_bytes) {
-  return static_cast<size_t>(sweep_block(key_bytes, value_bytes)) * sweep_items(key_bytes, value_bytes);
+size_t tile_keys(int key_bytes, int value_bytes, bool chain = false) {
+  return static_cast<size_t>(sweep_block(key_bytes, value_bytes, chain)) * sweep_items(key_bytes, value_bytes);
 }
-size_t tiles_for(size_t n, int key_bytes, int value_bytes) {
-  const size_t t = tile_keys(key_bytes, value_bytes);
+size_t tiles_for(size_t n, int key_bytes, int value_bytes, bool chain = false) {
+  const size_t t = tile_keys(key_bytes, value_bytes, chain);
   return (n + t - 1) / t;
 }
 // sized for the smaller (wide) tile so that one reservation serves every geometry
@@ -171,20 +181,21 @@ void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, bool 
   constexpr int kBlock = sweep_block(static_cast<int>(sizeof(K)), kVal);
   constexpr int kItems = sweep_items(static_cast<int>(sizeof(K)), kVal);
   constexpr int kMinBlocks = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
-  // (8-byte descriptors with the 16384-key tiles would need more LDS than two workgroups per CU leave: not built)
-  if constexpr (sizeof(K) >= 4 && !(sizeof(D) == 8 && narrow_geometry(static_cast<int>(sizeof(K)), kVal))) {
+  if constexpr (sizeof(K) >= 4) {
     if (chain) {   // persistent workgroups, one chain of tiles per XCD (only with the returning-add ranking)
+      constexpr int kBlockC = sweep_block(static_cast<int>(sizeof(K)), kVal, true);
+      constexpr int kMinBlocksC = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_CHAIN_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
       auto launch = [&](auto kernel) {
         static const int per_cu = [&] {      // resident workgroups per CU (registers, LDS, wave slots)
           int nb = 0;
-          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 1;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlockC, 0) != hipSuccess || nb < 1) nb = 1;
           return nb;
         }();
-        hipLaunchKernelGGL(kernel, dim3(chain_grid * per_cu), dim3(kBlock), 0, s, a);
+        hipLaunchKernelGGL(kernel, dim3(chain_grid * per_cu), dim3(kBlockC), 0, s, a);
       };
       // the last launched pass has no next digit to count for
-      if (a.next_cnt) launch(rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK_CHAIN, kMinBlocks, true, true, true>);
-      else launch(rsk::onesweep_kernel<K, V, D, kBlock, kItems, RS_LOOKBACK_CHAIN, kMinBlocks, true, true, false>);
+      if (a.next_cnt) launch(rsk::onesweep_kernel<K, V, D, kBlockC, kItems, RS_LOOKBACK_CHAIN, kMinBlocksC, true, true, true>);
+      else launch(rsk::onesweep_kernel<K, V, D, kBlockC, kItems, RS_LOOKBACK_CHAIN, kMinBlocksC, true, true, false>);
       return;
     }
   }
@@ -286,10 +297,20 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   if (n < 2) { c->ev_count = 0; return RS_OK; }
   hipStream_t s = c->stream;
   const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
-  const size_t tiles = tiles_for(n, key_bytes, value_bytes);
   // RSORT_FORCE_WIDE=1 (tests, A/B timing): 8-byte descriptors and offsets regardless of n
   static const bool force_wide = [] { const char* e = std::getenv("RSORT_FORCE_WIDE"); return e && e[0] == '1'; }();
   const bool wide = n > kSmallDescLimit || force_wide;
+  // Chain mode (rsort_kernels.hpp, "XCD chains"): one chain of tiles per XCD, swept by persistent workgroups.  For sorts
+  // large enough to keep every XCD busy with its own chain, on devices where the XCC-id probe found all eight XCDs, with
+  // the returning-add ranking, 4- and 8-byte keys, 16-byte aligned buffers (the histogram kernel counts per chain in
+  // 16-byte packs; the sweeps fetch their keys by 16-byte LDS-DMA).
+  static const long chain_min_tiles = [] { const char* e = std::getenv("RSORT_CHAIN_MIN_TILES"); return e ? std::atol(e) : 4096l; }();
+  static const bool chain_env = [] { const char* e = std::getenv("RSORT_CHAIN"); return !(e && e[0] == '0'); }();
+  const bool chain = chain_env && c->per_xcd_order && c->rank_by_lds_atomic && key_bytes >= 4 &&
+                     static_cast<long>(tiles_for(n, key_bytes, value_bytes, true)) >= chain_min_tiles &&
+                     (reinterpret_cast<uintptr_t>(keys) & 15u) == 0 && (reinterpret_cast<uintptr_t>(alt_keys) & 15u) == 0 &&
+                     n < (size_t(1) << 35);
+  const size_t tiles = tiles_for(n, key_bytes, value_bytes, chain);
   if (tiles > 0x7FFFFFFFull) return fail(c, RS_ERR_ARG, "n too large for one launch");
 
   const uint64_t sign = 1ull << (key_bytes * 8 - 1);
@@ -373,14 +394,6 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     }
   }
 
-  // Chain mode (rsort_kernels.hpp, "XCD chains"): one chain of tiles per XCD, swept by persistent workgroups.  For sorts
-  // large enough to keep every XCD busy with its own chain, on devices where the XCC-id probe found all eight XCDs, with
-  // the returning-add ranking, 4- and 8-byte keys, 16-byte aligned keys (the histogram kernel counts per chain in packs).
-  static const long chain_min_tiles = [] { const char* e = std::getenv("RSORT_CHAIN_MIN_TILES"); return e ? std::atol(e) : 4096l; }();
-  static const bool chain_env = [] { const char* e = std::getenv("RSORT_CHAIN"); return !(e && e[0] == '0'); }();
-  const bool chain = chain_env && c->per_xcd_order && c->rank_by_lds_atomic && key_bytes >= 4 &&
-                     static_cast<long>(tiles) >= chain_min_tiles && (reinterpret_cast<uintptr_t>(keys) & 15u) == 0 &&
-                     n < (size_t(1) << 35) && !(wide && narrow_geometry(key_bytes, value_bytes));
   unsigned chain_tiles = 0, chunk_shift = 0, chunk_mul = 0;
   if (chain) {
     // chains of U8 << r tiles, r such that positions >> (log2(tile) + r) stay below 256: the chain of an output position is
@@ -391,7 +404,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     const unsigned u8 = (u_max + rsk::kXcds - 1) / rsk::kXcds;
     chain_tiles = u8 << r;
     unsigned tile_log2 = 0;
-    while ((size_t(1) << tile_log2) < tile_keys(key_bytes, value_bytes)) ++tile_log2;
+    while ((size_t(1) << tile_log2) < tile_keys(key_bytes, value_bytes, true)) ++tile_log2;
     chunk_shift = tile_log2 + r;
     chunk_mul = (65536u + u8 - 1) / u8;
     for (unsigned u = 0; u < u_max; ++u)
@@ -409,7 +422,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   h.keys = keys; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
   h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
   h.chain_hist = chain ? chain_hist : nullptr;
-  h.chain_keys = chain ? static_cast<uint64_t>(chain_tiles) * tile_keys(key_bytes, value_bytes) : 0;
+  h.chain_keys = chain ? static_cast<uint64_t>(chain_tiles) * tile_keys(key_bytes, value_bytes, true) : 0;
   launch_hist(h, key_bytes, chain ? 256u * (key_bytes == 8 ? 1 : 2) : hist_grid(n, key_bytes), s);
   hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase,
                      static_cast<const unsigned long long*>(chain ? chain_hist : nullptr));

@@ -31,6 +31,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 // Diagnostic builds only, never defined in the product:
 //   -DRS_STAMPS   wave 0 / lane 0 of every 64th tile stores s_memrealtime (100 MHz) at phase
@@ -637,7 +638,23 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   // ---- load: wave-striped, so (item, lane) order == key order inside the wave's segment ----------
   K key[ITEMS];
   const unsigned seg = wave * (kWave * ITEMS) + lane;
-  if (full) {
+  if (full && CHAIN) {
+    // Chain mode (16-byte aligned buffers): the wave's segment comes in through LDS-DMA, 1 KB per instruction, into the
+    // staging area (idle at this point), and is read back striped.  A 4-byte-per-lane load costs the CU's address unit as
+    // much as a 16-byte one, and with single keys in both directions that unit, not HBM, bounds the pass (TA/TD 70-90 %
+    // busy, profiles/r02_a_pmc_*): this quarters its work for the loads.  Each wave reads only what it requested itself.
+    constexpr unsigned kSegBytes = kWave * ITEMS * sizeof(K);
+    unsigned char* land = s.stage + wave * kSegBytes;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(kin) + wave * kSegBytes + lane * 16;
+#pragma unroll
+    for (unsigned b = 0; b < kSegBytes; b += kWave * 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b),
+                                       (__attribute__((address_space(3))) void*)(land + b), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const K* lk = reinterpret_cast<const K*>(land);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) key[i] = lk[i * kWave + lane];
+  } else if (full) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) key[i] = kin[seg + i * kWave];
   } else {
@@ -862,19 +879,45 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   const K fmo = static_cast<K>(a.fmask_out), smo = static_cast<K>(a.smask_out);
   const bool xf_out = (a.fmask_out | a.smask_out) != 0;
   D dst[HAS_VAL ? ITEMS : 1];
-#pragma unroll
-  for (int i = 0; i < ITEMS; ++i) {
+  // One round of the write-out: staged key j = i * BLOCK + tid goes to its run.  Counting kernels also add the key to its
+  // (chain of the output position, next digit) cell.  PEEL selects how: 0 = one LDS add per key, straight-line code (a
+  // branch inside the rounds, even a wave-uniform one, keeps the compiler from overlapping their LDS reads and stores);
+  // 2 = the lanes that share the first lane's cell add once, through that lane, and so do the lanes that share the
+  // first remaining lane's cell.  The staged keys are in digit order, so on few-valued inputs the 64 lanes of a round
+  // hold one or two runs of EQUAL keys and would otherwise queue their adds on one or two words (256-value
+  // duplicates: 4.8 ms per uint32 pass instead of 2.1); on random keys the extra instructions cost 8 % of a pass,
+  // so every wave looks at its first round and picks the form for the other fifteen.
+  unsigned first_group = 0;          // lanes that shared the first lane's cell in round 0
+  auto write_round = [&](auto peel_tag, int i) {
+    constexpr int PEEL = decltype(peel_tag)::value;
     unsigned j = i * BLOCK + tid;
     if (full || j < tile_count) {
       K k = stage_k[stage_swizzle(j)];
       D o = s.gofs[digit_at(k, a.shift, a.bits)] + j;
-      if constexpr (CHAIN) {
-        if constexpr (COUNT) {
-          // (chain of the output position, next digit) -> one 16-bit cell; straight-line code on purpose: a branch here
-          // (even a wave-uniform one) keeps the compiler from overlapping the sixteen rounds' LDS reads and stores
-          const unsigned dn = digit_at(k, a.next_shift, a.next_bits);
-          const unsigned c = __umul24(static_cast<unsigned>(o >> a.chunk_shift), a.chunk_mul) >> 16;
+      if constexpr (CHAIN && COUNT) {
+        const unsigned dn = digit_at(k, a.next_shift, a.next_bits);
+        const unsigned c = __umul24(static_cast<unsigned>(o >> a.chunk_shift), a.chunk_mul) >> 16;
+        if constexpr (PEEL == 0) {
           atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], 1u << ((c & 1u) << 4));
+        } else {
+          const unsigned cell = (c << 8) | dn;
+          const unsigned long long act = __ballot(true);
+          const unsigned l0 = static_cast<unsigned>(__ffsll(static_cast<long long>(act)) - 1);
+          const unsigned cell0 = __builtin_amdgcn_readfirstlane(cell);
+          const unsigned long long g0 = __ballot(cell == cell0);
+          if constexpr (PEEL == 1) first_group = static_cast<unsigned>(__popcll(g0));   // round 0: measure, add one by one
+          unsigned add = 1u;
+          if constexpr (PEEL == 2) {
+            if (cell == cell0) add = lane == l0 ? static_cast<unsigned>(__popcll(g0)) : 0u;
+            const unsigned long long rest = act & ~g0;
+            if (rest) {                                   // wave-uniform
+              const unsigned l1 = static_cast<unsigned>(__ffsll(static_cast<long long>(rest)) - 1);
+              const unsigned cell1 = __builtin_amdgcn_readlane(cell, l1);
+              const unsigned long long g1 = __ballot(cell == cell1);
+              if (cell == cell1) add = lane == l1 ? static_cast<unsigned>(__popcll(g1)) : 0u;
+            }
+          }
+          if (add) atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], add << ((c & 1u) << 4));
         }
       }
       if constexpr (HAS_VAL || kCheckedStores) {
@@ -888,6 +931,19 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
         kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
       }
     }
+  };
+  if constexpr (CHAIN && COUNT) {
+    write_round(std::integral_constant<int, 1>{}, 0);
+    if (__builtin_amdgcn_readfirstlane(first_group) >= 8) {   // wave-uniform
+#pragma unroll
+      for (int i = 1; i < ITEMS; ++i) write_round(std::integral_constant<int, 2>{}, i);
+    } else {
+#pragma unroll
+      for (int i = 1; i < ITEMS; ++i) write_round(std::integral_constant<int, 0>{}, i);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) write_round(std::integral_constant<int, 0>{}, i);
   }
 #ifdef RS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

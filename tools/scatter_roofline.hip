@@ -62,6 +62,39 @@ __global__ __launch_bounds__(1024) void scatter_kernel_dword(const unsigned* in,
   }
 }
 
+// Chain order: persistent workgroups, chain = XCC id, tiles of a chain drawn front to back from the chain's own counter (the
+// order of the chain-mode sweep): every run boundary is shared by two tiles of one XCD.
+__device__ inline unsigned xcc_id_() { return static_cast<unsigned>(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20)) & 7u; }
+template <typename T>   // T = unsigned (4-byte lanes) or uint2 (8-byte lanes)
+__global__ __launch_bounds__(1024) void scatter_kernel_chain(const T* in, T* out, unsigned tiles, unsigned streams, unsigned run_e /* elements per run */,
+                                                             unsigned shift_e, unsigned* tickets) {
+  __shared__ unsigned s_tile;
+  constexpr unsigned tile_e = 65536 / sizeof(T);
+  constexpr unsigned per_thread = tile_e / 1024;
+  const unsigned chain = xcc_id_(), chain_tiles = (tiles + 7) / 8;
+  const unsigned first = chain * chain_tiles, end = min(first + chain_tiles, tiles);
+  const size_t stream_e = static_cast<size_t>(tiles) * tile_e / streams;
+  const unsigned runs_per_stream = tile_e / run_e / streams;
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = first + atomicAdd(&tickets[chain * 32], 1u);
+    __syncthreads();
+    const unsigned t = s_tile;
+    __syncthreads();
+    if (t >= end) break;
+    const T* src = in + static_cast<size_t>(t) * tile_e;
+    T v[per_thread];
+#pragma unroll
+    for (unsigned i = 0; i < per_thread; ++i) v[i] = src[i * 1024 + threadIdx.x];
+#pragma unroll
+    for (unsigned i = 0; i < per_thread; ++i) {
+      const unsigned j = i * 1024 + threadIdx.x;
+      const unsigned r = j / run_e, o = j % run_e;
+      const unsigned st = r % streams, k = r / streams;
+      out[static_cast<size_t>(st) * stream_e + (static_cast<size_t>(t) * runs_per_stream + k) * run_e + o + shift_e] = v[i];
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = argc > 1 ? strtoull(argv[1], 0, 10) << 20 : 4096ull << 20;
   const unsigned tiles = bytes / 65536;
@@ -94,5 +127,21 @@ int main(int argc, char** argv) {
     std::sort(ms.begin(), ms.end());
     printf("4-byte lanes: streams %4u run %6u B shift %3u B xcd-group %2u : %.3f ms  %.2f TB/s (read+write)\n", c[0], c[1], c[2], c[3], ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
   }
+  unsigned* tickets; CK(hipMalloc(&tickets, 8 * 32 * 4));
+  const unsigned cfgc[][3] = {{256, 256, 0}, {256, 256, 64}, {256, 256, 20}, {512, 128, 20}, {128, 512, 20}};
+  for (int wide = 0; wide < 2; ++wide)
+    for (auto& c : cfgc) {
+      std::vector<float> ms;
+      for (int it = 0; it < 7; ++it) {
+        CK(hipMemset(tickets, 0, 8 * 32 * 4));
+        CK(hipEventRecord(e0));
+        if (wide) hipLaunchKernelGGL(scatter_kernel_chain<uint2>, dim3(512), dim3(1024), 0, 0, reinterpret_cast<const uint2*>(in), reinterpret_cast<uint2*>(out), tiles, c[0], c[1] / 8, (c[2] + 7) / 8, tickets);
+        else hipLaunchKernelGGL(scatter_kernel_chain<unsigned>, dim3(512), dim3(1024), 0, 0, reinterpret_cast<const unsigned*>(in), reinterpret_cast<unsigned*>(out), tiles, c[0], c[1] / 4, c[2] / 4, tickets);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float m; CK(hipEventElapsedTime(&m, e0, e1)); if (it >= 2) ms.push_back(m);
+      }
+      std::sort(ms.begin(), ms.end());
+      printf("chain order, %d-byte lanes: streams %4u run %6u B shift %3u B : %.3f ms  %.2f TB/s (read+write)\n", wide ? 8 : 4, c[0], c[1], wide ? (c[2] + 7) / 8 * 8 : c[2], ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
+    }
   return 0;
 }
