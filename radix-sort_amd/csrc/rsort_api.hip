@@ -181,7 +181,7 @@ void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, bool 
   constexpr int kBlock = sweep_block(static_cast<int>(sizeof(K)), kVal);
   constexpr int kItems = sweep_items(static_cast<int>(sizeof(K)), kVal);
   constexpr int kMinBlocks = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
-  if constexpr (sizeof(K) >= 4) {
+  if constexpr (kVal == 0 ? sizeof(K) >= 4 : (sizeof(K) == 8 && kVal == 4)) {   // the shapes sort_device selects chain mode for
     if (chain) {   // persistent workgroups, one chain of tiles per XCD (only with the returning-add ranking)
       constexpr int kBlockC = sweep_block(static_cast<int>(sizeof(K)), kVal, true);
       constexpr int kMinBlocksC = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_CHAIN_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
@@ -306,7 +306,10 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // 16-byte packs; the sweeps fetch their keys by 16-byte LDS-DMA).
   static const long chain_min_tiles = [] { const char* e = std::getenv("RSORT_CHAIN_MIN_TILES"); return e ? std::atol(e) : 4096l; }();
   static const bool chain_env = [] { const char* e = std::getenv("RSORT_CHAIN"); return !(e && e[0] == '0'); }();
-  const bool chain = chain_env && c->per_xcd_order && c->rank_by_lds_atomic && key_bytes >= 4 &&
+  // Pairs: measured at N = 2^30 / 2^29, only 8-byte keys with a 4-byte payload gain (5.07 against 6.00 ms per pass; the
+  // other three pair kernels run out of registers in the persistent form and lose), so only those use it.
+  const bool chain_shape = value_bytes == 0 ? key_bytes >= 4 : (key_bytes == 8 && value_bytes == 4);
+  const bool chain = chain_env && c->per_xcd_order && c->rank_by_lds_atomic && chain_shape &&
                      static_cast<long>(tiles_for(n, key_bytes, value_bytes, true)) >= chain_min_tiles &&
                      (reinterpret_cast<uintptr_t>(keys) & 15u) == 0 && (reinterpret_cast<uintptr_t>(alt_keys) & 15u) == 0 &&
                      n < (size_t(1) << 35);
@@ -435,6 +438,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // (under 10 us each below kAlwaysSweepTiles tiles).
   int live[kMaxPasses];     // the passes that are launched, in order
   int n_live = 0;
+  int min_bins = 256;       // fewest digit values in use over the launched passes (known only with the counts on the host)
   if (tiles <= kAlwaysSweepTiles && passes <= 4) {
     for (int p = 0; p < passes; ++p) live[n_live++] = p;
   } else {
@@ -446,12 +450,27 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       for (int d = 0; d < 256; ++d)
         if (h_hist[p * 256 + d] == n) { constant = true; break; }
       if (!constant) live[n_live++] = p;
+      if (!constant) {
+        int bins = 0;
+        for (int d = 0; d < 256; ++d) bins += h_hist[p * 256 + d] != 0;
+        if (bins < min_bins) min_bins = bins;
+      }
     }
+  }
+  // Few-valued 4-byte keys (the 256-value "duplicates" shape: about 160 of 256 bins in use per pass) go down the
+  // one-chain kernels: staged in digit order, their equal keys sit next to each other, and the chain kernels' counting adds
+  // then cost more than the chained look-back saves (N = 2^30: 11.1 ms against 9.7 ms; 8-byte keys gain either way).
+  // The histogram and the zeroed descriptor rows serve both forms.
+  bool sweep_chain = chain;
+  size_t sweep_tiles = tiles;
+  if (chain && key_bytes == 4 && value_bytes <= 4 && min_bins < 200) {
+    sweep_chain = false;
+    sweep_tiles = tiles_for(n, key_bytes, value_bytes, false);
   }
 
   void* kin = keys; void* kout = alt_keys;
   void* vin = vals; void* vout = alt_vals;
-  const SweepLaunch launch{tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, chain, static_cast<unsigned>(c->cus), s};
+  const SweepLaunch launch{sweep_tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, sweep_chain, static_cast<unsigned>(c->cus), s};
   for (int done = 0; done < n_live; ++done) {
     const int p = live[done];
     rsk::SweepArgs a{};
@@ -462,9 +481,9 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.fmask_out = done == n_live - 1 ? fmask : 0; a.smask_out = done == n_live - 1 ? smask : 0;  // last launched pass
     a.shift = begin_bit + p * rsk::kRadixBits;
     a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
-    a.per_xcd_order = c->per_xcd_order && tiles >= kPerXcdMinTiles ? 1 : 0;
+    a.per_xcd_order = c->per_xcd_order && sweep_tiles >= kPerXcdMinTiles ? 1 : 0;
     a.incl_code = 2u + (done & 1);          // alternates over the LAUNCHED passes (descriptor parity, rsort_kernels.hpp)
-    if (chain) {
+    if (sweep_chain) {
       // this pass' digit counts per chain: from the histogram kernel for the first launched pass, from the previous sweep after that
       a.chain_cnt = done == 0 ? chain_hist + p * rsk::kRadix : next_cnt + static_cast<size_t>(done - 1) * rsk::kXcds * rsk::kRadix;
       a.chain_cnt_stride = done == 0 ? rsk::kChainHistStride : rsk::kRadix;

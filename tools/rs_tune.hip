@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
   if (f_st) {
     std::vector<unsigned long long> st(16 * 4096);
     f_st(st.data());
-    size_t tile_keys = (kb <= 4 && vb <= 4) ? 16384 : 8192; size_t tiles = (n + tile_keys - 1) / tile_keys, cnt = std::min<size_t>(tiles / 64, 4096);
+    size_t tile_keys = getenv("RS_TUNE_TILE") ? atoi(getenv("RS_TUNE_TILE")) : ((kb <= 4 && vb <= 4) ? 16384 : 8192); size_t tiles = (n + tile_keys - 1) / tile_keys, cnt = std::min<size_t>(tiles / 64, 4096);
     const char* names[] = {"begin->ticket", "ticket->counted", "counted->ranked", "ranked->scanned", "scanned->staged", "staged->lookedback", "lookedback->written"};
     for (int k = 0; k < 7; ++k) {
       std::vector<double> d;
@@ -114,7 +114,7 @@ int main(int argc, char** argv) {
   if (f_st) {
     std::vector<unsigned long long> st(16 * 4096);
     f_st(st.data());
-    size_t tile_keys = (kb <= 4 && vb <= 4) ? 16384 : 8192; size_t tiles = (n + tile_keys - 1) / tile_keys, cnt = std::min<size_t>(tiles / 64, 4096);
+    size_t tile_keys = getenv("RS_TUNE_TILE") ? atoi(getenv("RS_TUNE_TILE")) : ((kb <= 4 && vb <= 4) ? 16384 : 8192); size_t tiles = (n + tile_keys - 1) / tile_keys, cnt = std::min<size_t>(tiles / 64, 4096);
     const char* nm[] = {"lookback trips", "empty trips", "tiles walked"};
     for (int k = 0; k < 3; ++k) {
       std::vector<double> d;
