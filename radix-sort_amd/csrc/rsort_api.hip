@@ -97,6 +97,8 @@ struct rs_ctx {
   bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create (and cleared by rs_ctx_set_tile_order)
   bool per_xcd_probe_ok = false;     // what the probe found
   int cus = 256;                     // compute units of the device (persistent grids: 2 workgroups each)
+  char* static_scratch = nullptr;    // this device's copy of rs_static_scratch (rs_sort_keys_device_noalloc)
+  bool static_used = false;          // a sort has used it since its error word was last read
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   bool last_unchanged = false;   // the last sort_device found its input already in order and moved nothing
@@ -118,6 +120,18 @@ constexpr size_t kCtrlBytes = kCtrlError + 64;   // error word at +0, order-chec
 constexpr size_t kCtrlChainHist = (kCtrlBytes + 255) & ~size_t(255);                       // u64 [8 chains][8 passes][256] from the histogram kernel
 constexpr size_t kCtrlNextCnt = kCtrlChainHist + rsk::kXcds * rsk::kChainHistStride * 8;   // u64 [8 passes][8 chains][256] from the sweeps
 constexpr size_t kCtrlBytesChain = kCtrlNextCnt + kMaxPasses * rsk::kXcds * 256 * 8;
+
+// Workspace of the entry point that allocates nothing (rs_sort_keys_device_noalloc): control block and look-back
+// descriptors in a static device array instead of hipMalloc'ed memory.  Every GPU the library runs on holds its own copy
+// until the process ends; all calls on one GPU share it.
+constexpr size_t kNoAllocMaxKeys = size_t(1) << 25;
+constexpr size_t kNoAllocCtrlBytes = (kCtrlBytes + 255) & ~size_t(255);
+constexpr size_t kNoAllocDescBytes = (kNoAllocMaxKeys / 8192) * 256 * 4;     // smallest tile of any geometry, 4-byte descriptors
+constexpr size_t kNoAllocBytes = kNoAllocCtrlBytes + kNoAllocDescBytes;       // 4.02 MiB
+struct Workspace {        // non-null: sort_device uses these and neither allocates nor waits for the device
+  char* ctrl;
+  void* desc;
+};
 
 int fail(rs_ctx* c, int code, const std::string& msg) {
   if (c) c->err = msg;
@@ -145,6 +159,7 @@ int ensure(rs_ctx* c, DevBuf& b, size_t bytes) {
     return fail(c, RS_ERR_NOMEM, "hipMalloc(" + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
   }
   b.bytes = bytes;
+  if (&b == &c->ctrl) RS_HIP(c, hipMemsetAsync(b.p, 0, bytes, c->stream));   // the error word starts clear and is only cleared again once read
   return RS_OK;
 }
 
@@ -292,7 +307,7 @@ void launch_reverse_k(void* keys, size_t n, hipStream_t s) {
 
 // The device sort proper.  keys/vals are sorted in place; alt_* are same-size scratch.
 int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_vals, size_t n, int key_bytes,
-                int value_bytes, int transform, int begin_bit, int end_bit) {
+                int value_bytes, int transform, int begin_bit, int end_bit, const Workspace* ws = nullptr) {
   c->last_unchanged = false;
   if (n < 2) { c->ev_count = 0; return RS_OK; }
   hipStream_t s = c->stream;
@@ -309,7 +324,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // Pairs: measured at N = 2^30 / 2^29, only 8-byte keys with a 4-byte payload gain (5.07 against 6.00 ms per pass; the
   // other three pair kernels run out of registers in the persistent form and lose), so only those use it.
   const bool chain_shape = value_bytes == 0 ? key_bytes >= 4 : (key_bytes == 8 && value_bytes == 4);
-  const bool chain = chain_env && c->per_xcd_order && c->rank_by_lds_atomic && chain_shape &&
+  const bool chain = !ws && chain_env && c->per_xcd_order && c->rank_by_lds_atomic && chain_shape &&
                      static_cast<long>(tiles_for(n, key_bytes, value_bytes, true)) >= chain_min_tiles &&
                      (reinterpret_cast<uintptr_t>(keys) & 15u) == 0 && (reinterpret_cast<uintptr_t>(alt_keys) & 15u) == 0 &&
                      n < (size_t(1) << 35);
@@ -340,8 +355,12 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   }
 
   int rc;
-  if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
-  if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
+  if (!ws) {
+    if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
+    if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
+  } else {
+    c->static_used = true;
+  }
   if (!alt_keys) {
     if ((rc = ensure(c, c->alt_keys, n * key_bytes)) != RS_OK) return rc;
     alt_keys = c->alt_keys.p;
@@ -351,7 +370,8 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     alt_vals = c->alt_vals.p;
   }
 
-  char* ctrl = static_cast<char*>(c->ctrl.p);
+  char* ctrl = ws ? ws->ctrl : static_cast<char*>(c->ctrl.p);
+  void* const desc = ws ? ws->desc : c->desc.p;
   auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);
   auto* gbase = reinterpret_cast<unsigned long long*>(ctrl + kCtrlBase);
   auto* tickets = reinterpret_cast<unsigned*>(ctrl + kCtrlTicket);
@@ -359,7 +379,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
 
   // Order pre-check (isSortedBi :269-305 / key::isSorted :746-769): ascending on the sorted field -> nothing to do
   // (a stable sort of ordered input is the identity); descending, whole key, no payload -> reverse in place.
-  if (c->precheck) {
+  if (c->precheck && !ws) {
     rsk::OrderArgs o{};
     o.keys = keys; o.flags = error_flag + 8; o.n = n; o.fmask = fmask; o.smask = smask;
     o.begin_bit = begin_bit; o.bits = end_bit - begin_bit;
@@ -416,8 +436,10 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
 
   int ev = 0;
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
-  RS_HIP(c, hipMemsetAsync(ctrl, 0, chain ? kCtrlBytesChain : kCtrlBytes, s));
-  RS_HIP(c, hipMemsetAsync(c->desc.p, 0, tiles * 256 * (wide ? 8 : 4), s));   // the rows this sort uses, not the whole reservation
+  // counts, bases and tickets; NOT the error word behind them: it keeps a fault until check_kernel_error has read it
+  RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlError, s));
+  if (chain) RS_HIP(c, hipMemsetAsync(ctrl + kCtrlChainHist, 0, kCtrlBytesChain - kCtrlChainHist, s));
+  RS_HIP(c, hipMemsetAsync(desc, 0, tiles * 256 * (wide ? 8 : 4), s));   // the rows this sort uses, not the whole reservation
 
   auto* chain_hist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlChainHist);
   auto* next_cnt = reinterpret_cast<unsigned long long*>(ctrl + kCtrlNextCnt);
@@ -439,7 +461,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   int live[kMaxPasses];     // the passes that are launched, in order
   int n_live = 0;
   int min_bins = 256;       // fewest digit values in use over the launched passes (known only with the counts on the host)
-  if (tiles <= kAlwaysSweepTiles && passes <= 4) {
+  if (ws || (tiles <= kAlwaysSweepTiles && passes <= 4)) {
     for (int p = 0; p < passes; ++p) live[n_live++] = p;
   } else {
     unsigned long long h_hist[kMaxPasses * 256];
@@ -475,7 +497,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     const int p = live[done];
     rsk::SweepArgs a{};
     a.keys_in = kin; a.keys_out = kout; a.vals_in = vin; a.vals_out = vout;
-    a.desc = c->desc.p; a.ticket = tickets + p * rsk::kTicketWords; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
+    a.desc = desc; a.ticket = tickets + p * rsk::kTicketWords; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
     a.n = n;
     a.fmask_in = done == 0 ? fmask : 0; a.smask_in = done == 0 ? smask : 0;                    // first launched pass
     a.fmask_out = done == n_live - 1 ? fmask : 0; a.smask_out = done == n_live - 1 ? smask : 0;  // last launched pass
@@ -509,16 +531,20 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   return RS_OK;
 }
 
+// Waits for the stream, then reports (and clears) a fault that any sort queued since the last call left in an error word:
+// the word is not part of the per-sort memset and kernels only OR into it, so a fault is neither lost to a later sort
+// nor reported twice.
 int check_kernel_error(rs_ctx* c) {
-  unsigned flag = 0;
+  unsigned flag = 0, sflag = 0;
   char* ctrl = static_cast<char*>(c->ctrl.p);
-  if (!ctrl) {                             // only single-workgroup sorts so far: no error word yet, but still a wait
-    RS_HIP(c, hipStreamSynchronize(c->stream));
-    return RS_OK;
-  }
-  RS_HIP(c, hipMemcpyAsync(&flag, ctrl + kCtrlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
-  RS_HIP(c, hipStreamSynchronize(c->stream));
-  if (flag == 2)
+  if (ctrl) RS_HIP(c, hipMemcpyAsync(&flag, ctrl + kCtrlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
+  if (c->static_used) RS_HIP(c, hipMemcpyAsync(&sflag, c->static_scratch + kCtrlError, sizeof(sflag), hipMemcpyDeviceToHost, c->stream));
+  RS_HIP(c, hipStreamSynchronize(c->stream));      // (also the wait when only single-workgroup sorts ran: no error word yet)
+  c->static_used = false;
+  if (flag) RS_HIP(c, hipMemsetAsync(ctrl + kCtrlError, 0, sizeof(flag), c->stream));
+  if (sflag) RS_HIP(c, hipMemsetAsync(c->static_scratch + kCtrlError, 0, sizeof(sflag), c->stream));
+  flag |= sflag;
+  if (flag & 2u)
     return fail(c, RS_ERR_KERNEL, "an output offset fell outside the array: the keys changed while the sort was running "
                                   "(the stream that produces them was not waited for?); the result is not a sort of the input");
   if (flag) return fail(c, RS_ERR_KERNEL, "onesweep look-back timed out (descriptor chain broken)");
@@ -597,6 +623,19 @@ int rs_debug_read_stamps(unsigned long long* dst) {   // diagnostic builds only;
   return hipMemcpyFromSymbol(dst, HIP_SYMBOL(rs_stamp_buf), sizeof(unsigned long long) * 16 * 4096) == hipSuccess ? 0 : 2;
 }
 #endif
+
+// Test hook, not in rsort_hip.h: ORs `code` into the context's error word on its stream, as a faulting sweep kernel would
+// (tests/test_gpu_errors.py checks that the fault is reported once, by the next synchronisation, whatever was queued behind it).
+int rs_debug_inject_fault(rs_ctx* c, unsigned code) {
+  if (!c) return RS_ERR_ARG;
+  RS_HIP(c, hipSetDevice(c->device));
+  int rc = ensure(c, c->ctrl, kCtrlBytesChain);
+  if (rc != RS_OK) return rc;
+  hipLaunchKernelGGL(rsk::inject_fault_kernel, dim3(1), dim3(1), 0, c->stream,
+                     reinterpret_cast<unsigned*>(static_cast<char*>(c->ctrl.p) + kCtrlError), code);
+  RS_HIP(c, hipGetLastError());
+  return RS_OK;
+}
 
 int rs_ctx_create(rs_ctx** out, int device) {
   if (!out) return RS_ERR_ARG;
@@ -783,7 +822,7 @@ int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, cons
   const uint64_t fmask = transform == RS_XF_IEEE ? all : 0;
   const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
 
-  RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlBytes, s));
+  RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlError, s));       // (not the error word: see sort_device)
   RS_HIP(c, hipMemsetAsync(c->desc.p, 0, tiles * 256 * (wide ? 8 : 4), s));
   rsk::HistArgs h{};
   h.keys = d_keys_in; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;

@@ -492,6 +492,11 @@ __global__ __launch_bounds__(256) void lds_order_probe_kernel(unsigned* violatio
 
 struct NoVal {};
 
+// test hook (rs_debug_inject_fault): what a faulting sweep does to the error word
+__global__ void inject_fault_kernel(unsigned* error_flag, unsigned code) {
+  __hip_atomic_fetch_or(error_flag, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Staging-area swizzle.  A key staged at tile-local sorted position p lives at element p ^ ((p >> 6) & 31).  On
 // ordered inputs every digit's run in a tile has (nearly) the same power-of-two length, so the lanes of one staging
 // store -- same rank, different digits -- would otherwise all fall on one LDS bank (measured: 4.4x the bank-conflict
@@ -854,7 +859,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
         rs_stamp_buf[10 * 4096 + (tile >> 6)] = static_cast<unsigned long long>(static_cast<long long>(tile) - 1 - t);
       }
 #endif
-      if (failed) __hip_atomic_store(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (failed) __hip_atomic_fetch_or(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       D word = (static_cast<D>(a.incl_code) << Desc<D>::kShift) |
                (static_cast<D>(excl + my_count) & Desc<D>::kValueMask);
       desc_store<CHAIN>(&desc[tile * kRadix + tid], word);
@@ -870,7 +875,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   __syncthreads();
   RS_STAMP(6);
   if (s.out_of_range) {                            // workgroup-uniform
-    if (tid == 0) __hip_atomic_store(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_or(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     break;
   }
 
@@ -926,7 +931,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
         const bool inside = static_cast<uint64_t>(o) < a.n;
         if (inside) kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
         if constexpr (HAS_VAL) dst[i] = inside ? o : ~static_cast<D>(0);
-        if constexpr (kCheckedStores) { if (!inside) __hip_atomic_store(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if constexpr (kCheckedStores) { if (!inside) __hip_atomic_fetch_or(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
       } else {
         kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
       }

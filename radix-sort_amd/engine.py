@@ -53,6 +53,13 @@ class Engine:
             import torch
             torch.cuda.current_stream(t.device).synchronize()
 
+    def _finish_for_torch(self):
+        """Tensor entry points only: on the context's own stream nothing orders torch's work behind the sort, so the
+        call waits for it (and surfaces RS_ERR_KERNEL); with an attached stream the sort is ordered on that stream and
+        the call returns once it is queued.  The raw *_ptr variants never wait: follow them with synchronize()."""
+        if self._own_stream:
+            self.synchronize()
+
     def reserve(self, n, key_bytes, value_bytes=0):
         self._ck(self.lib.rs_ctx_reserve(self.h, n, key_bytes, value_bytes))
 
@@ -116,6 +123,7 @@ class Engine:
         self._wait_for_torch(t)
         self.sort_keys_ptr(t.data_ptr(), t.numel(), t.element_size(), transform,
                            alt.data_ptr() if alt is not None else None, begin_bit, end_bit)
+        self._finish_for_torch()
         return t
 
     def sort_pairs_(self, k, v, transform, alt_k=None, alt_v=None, begin_bit=0, end_bit=None):
@@ -124,6 +132,7 @@ class Engine:
         self.sort_pairs_ptr(k.data_ptr(), v.data_ptr(), k.numel(), k.element_size(), v.element_size(), transform,
                             alt_k.data_ptr() if alt_k is not None else None,
                             alt_v.data_ptr() if alt_v is not None else None, begin_bit, end_bit)
+        self._finish_for_torch()
         return k, v
 
     # ---- host numpy arrays (H2D + sort + D2H inside the library) -----------------------------------

@@ -43,3 +43,44 @@ def test_bad_arguments_are_rejected_with_a_message():
     assert lib.rs_sort_keys_device(eng.h, p, q, 0, 4, 0, 0, 32) == RS_OK
     assert lib.rs_sort_keys_device(eng.h, p, q, 1, 4, 0, 0, 32) == RS_OK
     eng.close()
+
+
+def test_kernel_fault_is_reported_once_and_not_lost():
+    """The device error word (include/rsort_hip.h: rs_ctx_synchronize 'reports a fault of any sort queued since the last
+    call'): a fault survives sorts queued behind it, is reported by the next synchronisation, and does not stick to later
+    calls.  The fault is injected by the library's test hook (what a sweep kernel does when an output offset leaves the
+    array), so the test does not depend on winning a race against a running sort."""
+    import torch
+    lib = rs.load_library()
+    lib.rs_debug_inject_fault.restype = C.c_int
+    lib.rs_debug_inject_fault.argtypes = [C.c_void_p, C.c_uint]
+    eng = rs.Engine(0)
+    eng.set_precheck(False)
+    RS_ERR_KERNEL = 3
+    big = torch.randint(0, 2**31 - 1, (3_000_000,), dtype=torch.int32, device="cuda")
+    small = torch.randint(0, 2**31 - 1, (500,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    # a fault, then two more sorts queued behind it (one multi-tile, whose start-of-sort memsets must not wipe it; one single-tile)
+    assert lib.rs_debug_inject_fault(eng.h, 2) == RS_OK
+    eng.sort_keys_ptr(big.data_ptr(), big.numel(), 4, 1)
+    eng.sort_keys_ptr(small.data_ptr(), small.numel(), 4, 1)
+    rc = lib.rs_ctx_synchronize(eng.h)
+    assert rc == RS_ERR_KERNEL, rc
+    assert b"outside the array" in lib.rs_last_error(eng.h)
+    # reported once: the next calls are clean, small and large, device and host entry points
+    assert lib.rs_ctx_synchronize(eng.h) == RS_OK
+    eng.sort_keys_ptr(small.data_ptr(), small.numel(), 4, 1)
+    assert lib.rs_ctx_synchronize(eng.h) == RS_OK
+    v = np.array([5, 3, 9, 1], dtype=np.uint32)
+    assert eng.sort_keys_host(v, 0).tolist() == [1, 3, 5, 9]
+    big2 = torch.randint(0, 2**31 - 1, (3_000_000,), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eng.sort_keys_ptr(big2.data_ptr(), big2.numel(), 4, 1)
+    assert lib.rs_ctx_synchronize(eng.h) == RS_OK
+    assert bool((big2[1:] >= big2[:-1]).all())
+    # a look-back timeout code (1) is reported with its own message
+    assert lib.rs_debug_inject_fault(eng.h, 1) == RS_OK
+    assert lib.rs_ctx_synchronize(eng.h) == RS_ERR_KERNEL
+    assert b"look-back" in lib.rs_last_error(eng.h)
+    assert lib.rs_ctx_synchronize(eng.h) == RS_OK
+    eng.close()
