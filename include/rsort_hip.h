@@ -101,6 +101,21 @@ int rs_ctx_get_profile(rs_ctx* ctx, float* ms, int capacity, int* count);
 int rs_sort_keys_device(rs_ctx* ctx, void* d_keys, void* d_alt, size_t n, int key_bytes,
                         int transform, int begin_bit, int end_bit);
 
+/* rs_sort_keys_device_noalloc: rs_sort_keys_device for callers that cannot allocate device memory -- code under HIP
+ *   graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference (a CPU library
+ *   whose every call allocates its temporaries, radix_sort.hpp:510, :646).  Same result as rs_sort_keys_device, bit for bit.
+ *   It calls no hipMalloc / hipFree and no allocating library routine, and it does not wait for the device: memsets and
+ *   kernels are queued on the context's stream and the call returns.  Consequently: d_alt (n*key_bytes bytes) is
+ *   required; there is no order pre-check and no pass skipping (both need counts on the host); n <= RS_NOALLOC_MAX_KEYS,
+ *   larger n is rejected with RS_ERR_ARG.  Histograms, tickets and look-back descriptors live in a static device array of
+ *   4.06 MiB that every GPU the library runs on holds until the process ends.  All calls on one GPU share that array:
+ *   calls that overlap on one GPU (two streams, two contexts, two threads) race and must be serialised by the caller;
+ *   each call clears what it needs at its start.  A fault is reported by the next rs_ctx_synchronize, as for the other
+ *   device entry points. */
+#define RS_NOALLOC_MAX_KEYS ((size_t)1 << 25)
+int rs_sort_keys_device_noalloc(rs_ctx* ctx, void* d_keys, void* d_alt, size_t n, int key_bytes,
+                                int transform, int begin_bit, int end_bit);
+
 /* rs_sort_pairs_device: STABLE ascending sort of (key, value) pairs in place; value_bytes 4 or 8.
  *   Result == the key path of the reference (radix_sort.hpp:1160-1206 pair sortLsd,
  *   :1062-1109 pair scatter): with values = 0..n-1 the value column is the permutation that

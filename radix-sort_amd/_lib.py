@@ -24,6 +24,7 @@ SYMBOLS = [
     ("rs_ctx_set_profiling", _i, [_vp, _i]),
     ("rs_ctx_get_profile", _i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     ("rs_sort_keys_device", _i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i]),
+    ("rs_sort_keys_device_noalloc", _i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i]),
     ("rs_sort_pairs_device", _i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i]),
     ("rs_digit_histogram_device", _i, [_vp, _vp, _sz, _i, _i, _i, _i, _vp]),
     ("rs_partition_device", _i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),

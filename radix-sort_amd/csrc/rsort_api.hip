@@ -19,6 +19,9 @@
 #include "rsort_kernels.hpp"
 #include "rsort_strings.hpp"
 
+// see Workspace below; named only in rs_ctx_create (hipGetSymbolAddress), everything else uses the address kept in the context
+static __device__ __align__(256) unsigned char rs_static_scratch[(size_t(1) << 22) + 65536];
+
 namespace {
 
 constexpr int kMaxPasses = 8;
@@ -656,6 +659,14 @@ int rs_ctx_create(rs_ctx** out, int device) {
   }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { rs_ctx_destroy(c); return RS_ERR_HIP; }
+  // this device's copy of the static workspace (the array's name is only a host-side handle: kernels and memsets get
+  // the address looked up here, with the device current)
+  static_assert(sizeof(rs_static_scratch) >= kNoAllocBytes, "static workspace too small");
+  {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(rs_static_scratch)) != hipSuccess || !p) { rs_ctx_destroy(c); return RS_ERR_HIP; }
+    c->static_scratch = static_cast<char*>(p);
+  }
   // Ranking shortcut: usable only if returning LDS adds of one wave instruction are served in lane order.
   // Probed here on this device (about 2 million lane-operations over six collision patterns); any violation,
   // or any failure of the probe itself, keeps the ballot-based ranking.
@@ -781,6 +792,19 @@ int rs_sort_keys_device(rs_ctx* c, void* d_keys, void* d_alt, size_t n, int key_
   if (rc != RS_OK) return rc;
   RS_HIP(c, hipSetDevice(c->device));
   return sort_device(c, d_keys, nullptr, d_alt, nullptr, n, key_bytes, 0, transform, begin_bit, end_bit);
+}
+
+int rs_sort_keys_device_noalloc(rs_ctx* c, void* d_keys, void* d_alt, size_t n, int key_bytes, int transform,
+                                int begin_bit, int end_bit) {
+  int rc = check_args(c, d_keys, n, key_bytes, 0, transform, begin_bit, end_bit);
+  if (rc != RS_OK) return rc;
+  if (n > kNoAllocMaxKeys)
+    return fail(c, RS_ERR_ARG, "rs_sort_keys_device_noalloc sorts at most " + std::to_string(kNoAllocMaxKeys) +
+                               " keys (its workspace is a fixed static device array); use rs_sort_keys_device");
+  if (n > 1 && !d_alt) return fail(c, RS_ERR_ARG, "rs_sort_keys_device_noalloc needs the caller's alternate buffer (it allocates nothing)");
+  RS_HIP(c, hipSetDevice(c->device));
+  const Workspace ws{c->static_scratch, c->static_scratch + kNoAllocCtrlBytes};
+  return sort_device(c, d_keys, nullptr, d_alt, nullptr, n, key_bytes, 0, transform, begin_bit, end_bit, &ws);
 }
 
 int rs_sort_pairs_device(rs_ctx* c, void* d_keys, void* d_values, void* d_alt_keys, void* d_alt_values,

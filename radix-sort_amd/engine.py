@@ -92,6 +92,12 @@ class Engine:
         self._ck(self.lib.rs_sort_keys_device(self.h, C.c_void_p(d_keys), C.c_void_p(d_alt or None), n,
                                               key_bytes, transform, begin_bit, end_bit))
 
+    def sort_keys_noalloc_ptr(self, d_keys, d_alt, n, key_bytes, transform, begin_bit=0, end_bit=None):
+        """rs_sort_keys_device_noalloc: static device workspace, nothing allocated, nothing waited for (n <= 2^25)."""
+        end_bit = key_bytes * 8 if end_bit is None else end_bit
+        self._ck(self.lib.rs_sort_keys_device_noalloc(self.h, C.c_void_p(d_keys), C.c_void_p(d_alt or None), n,
+                                                      key_bytes, transform, begin_bit, end_bit))
+
     def sort_pairs_ptr(self, d_keys, d_vals, n, key_bytes, value_bytes, transform, d_alt_keys=None,
                        d_alt_vals=None, begin_bit=0, end_bit=None):
         end_bit = key_bytes * 8 if end_bit is None else end_bit
