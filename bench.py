@@ -9,7 +9,11 @@ reference's harness copies its vector outside the timer (benchmark.cpp:158-160).
 
 N = 1 : workload = BASELINE configs[1]: uint32 and uint64, five generator shapes, N = 2^30, LSD
         onesweep on one MI355X.  `value` is the uint32 / randomized row (the case BASELINE's metric is
-        quoted on first); every (type, shape) row is in `rows`.
+        quoted on first); every (type, shape) row is in `rows`.  Behind them, with fewer repetitions:
+        configs[2] (int64 / float / double x randomized, duplicates), stable key+payload pair sorts
+        (`pair_rows`), the string-key sort through the C-ABI (`string_rows`) and configs[3], the
+        composite {std::string key; long long data} projected sort through include/radix_sort.hpp
+        (`composite_row`, tools/frontend_bench).
 N > 1 : BASELINE configs[4]: uint64 keys, N/GPU = --keys, MSD splitter + all-to-all + local LSD sort
         (radix-sort_amd/dist.py); `value` = total keys over all ranks / max-over-ranks time.
 
@@ -79,25 +83,27 @@ def bench_single(args):
     rows = []
     headline = None
     dominant = None
-    for name in args.types:
+    plan = [(name, args.shapes, args.steps, args.warmup) for name in args.types]
+    plan += [(name, args.extra_shapes, args.extra_steps, 1) for name in args.extra_types if name not in args.types]
+    for name, shape_list, steps, warmup in plan:
         dt, kb, xf = shapes.KEY_TYPES[name]
         eng.reserve(n, kb, 0)
         work = torch.empty(n, dtype=torch.int32 if kb == 4 else torch.int64, device=dev)
         alt = torch.empty_like(work)
-        for shape in args.shapes:
+        for shape in shape_list:
             src = shapes.generate_device(name, n, shape, dev)
 
             def timed(precheck):
                 eng.set_precheck(precheck)
                 times, pass_ms, hist_ms = [], [], []
-                for it in range(args.warmup + args.steps):
+                for it in range(warmup + steps):
                     work.copy_(src)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     eng.sort_keys_(work, xf, alt=alt)
                     eng.synchronize()
                     t1 = time.perf_counter()
-                    if it >= args.warmup:
+                    if it >= warmup:
                         times.append(t1 - t0)
                         prof = eng.profile()          # empty when the order pre-check answered the call
                         if prof:
@@ -138,7 +144,7 @@ def bench_single(args):
                 headline = row
                 avg_pass = (row["pass_ms"] if row["pass_ms"] else row["full_sort"]["pass_ms"]) * 1e-3
                 achieved = n * 2 * kb / avg_pass / 1e9
-                dominant = {"bound": "hbm", "kernel": f"onesweep_kernel<{name}>", "achieved": achieved,
+                dominant = {"bound": "hbm", "kernel": f"onesweep_kernel<{name}> (all launches of one sort: the counting and the last-pass instantiation of the chain-mode sweep)", "achieved": achieved,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": load_traffic(name),
                             "bytes_per_launch": n * 2 * kb, "avg_launch_ms": avg_pass * 1e3,
@@ -146,8 +152,111 @@ def bench_single(args):
             del src
         del work, alt
         torch.cuda.empty_cache()
+    pair_rows = [bench_pairs(eng, torch, dev, spec, args) for spec in args.pairs]
+    eng.set_profiling(False)
+    string_rows = [bench_strings(eng, m) for m in args.strings]
     eng.close()
-    return headline, rows, dominant
+    return headline, rows, dominant, pair_rows, string_rows
+
+
+def bench_pairs(eng, torch, dev, spec, args):
+    """Stable (key, payload) sort, device-resident: keys randomized, payload = 0..n-1 (the permutation sortByIndices
+    applies, radix_sort.hpp:1111-1154).  Canonical bytes B = K + 2P(K+V).  Checked at full size: keys ascending,
+    keys_out == keys_in[payload] (the payload is the permutation), equal neighbours keep payload order (stability)."""
+    from radix_sort_amd import shapes
+    name, vb = spec.split("+")
+    vb = int(vb)
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    n = min(args.n, args.pairs_n)
+    src = shapes.generate_device(name, n, "randomized", dev)
+    kdt = torch.int32 if kb == 4 else torch.int64
+    vdt = torch.int32 if vb == 4 else torch.int64
+    keys = torch.empty(n, dtype=kdt, device=dev)
+    vals = torch.empty(n, dtype=vdt, device=dev)
+    alt_k, alt_v = torch.empty_like(keys), torch.empty_like(vals)
+    iota = torch.arange(n, dtype=vdt, device=dev)
+    eng.set_precheck(True)
+    times, pass_ms = [], []
+    for it in range(1 + args.extra_steps):
+        keys.copy_(src)
+        vals.copy_(iota)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.sort_pairs_(keys, vals, xf, alt_k=alt_k, alt_v=alt_v)
+        eng.synchronize()
+        t1 = time.perf_counter()
+        if it >= 1:
+            times.append(t1 - t0)
+            pass_ms.extend(eng.profile()[1:])
+    del alt_k, alt_v, iota
+    sign = -(1 << 31) if kb == 4 else -(1 << 63)
+    okey = keys if xf == 1 else (keys ^ sign if xf == 0 else torch.where(keys < 0, ~keys ^ sign, keys))
+    asc = okey[1:] >= okey[:-1]
+    stable = ((okey[1:] != okey[:-1]) | (vals[1:] > vals[:-1]))
+    ok_sorted = bool(asc.all().item())
+    ok_stable = bool(stable.all().item())
+    del asc, stable, okey
+    ok_perm = bool((keys == src[vals.to(torch.int64)]).all().item())
+    sec = sum(times) / len(times)
+    b_key = algorithmic_bytes_per_key(kb, vb)
+    return {"type": name, "value_bytes": vb, "shape": "randomized", "n": n, "ms": sec * 1e3, "gkeys_s": n / sec / 1e9,
+            "bytes_per_key": b_key, "hbm_frac": n * b_key / sec / 1e9 / HBM_PEAK_GBS,
+            "pass_ms": sum(pass_ms) / len(pass_ms) if pass_ms else None,
+            "sorted": ok_sorted, "stable": ok_stable, "checksum": ok_perm}
+
+
+def bench_strings(eng, m):
+    """rs_sort_strings through the C-ABI: m strings of 0..20 uniform bytes (generators.hpp:264-291) in host memory, the
+    permutation back in host memory (upload and download included: the entry point takes host buffers).  Checked:
+    the result is a permutation and 200,000 sampled neighbour pairs are in std::string order, ties by index."""
+    import numpy as np
+    rng = np.random.default_rng(69)
+    lens = rng.integers(0, 21, size=m, dtype=np.int64)
+    offsets = np.zeros(m + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:].view(np.int64))
+    blob = rng.integers(0, 256, size=int(offsets[-1]), dtype=np.uint8)
+    eng.sort_strings_host(blob[: 1 << 16], offsets[:1001].copy())          # warm-up (context, kernels)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        perm = eng.sort_strings_host(blob, offsets, stable=True)
+        times.append(time.perf_counter() - t0)
+    ok_perm = bool((np.bincount(perm.astype(np.int64), minlength=m) == 1).all())
+    idx = rng.integers(0, m - 1, size=200_000)
+    ok_order = True
+    raw = blob.tobytes()
+    off = offsets.astype(np.int64)
+    for i in idx:
+        a, b = int(perm[i]), int(perm[i + 1])
+        sa, sb = raw[off[a]:off[a + 1]], raw[off[b]:off[b + 1]]
+        if sa > sb or (sa == sb and a > b):
+            ok_order = False
+            break
+    sec = min(times)
+    moved = int(offsets[-1]) + 8 * (m + 1) + 8 * m
+    return {"strings": m, "ms": sec * 1e3, "mstrings_s": m / sec / 1e6, "host_bytes_per_string": moved / m,
+            "includes": "H2D of blob+offsets, MSD sort, D2H of the permutation", "sorted": ok_order, "checksum": ok_perm}
+
+
+def bench_composite(n):
+    """BASELINE configs[3]: {std::string key; long long data}, projected-key sort through the drop-in header, host vectors in
+    and out, checked against std::stable_sort element by element (tools/frontend_bench.cpp)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "frontend_bench")
+    if not os.path.exists(exe):
+        return {"error": "tools/frontend_bench not built"}
+    try:
+        out = subprocess.run([exe, "1000", str(n)], capture_output=True, text=True, timeout=600).stdout
+    except Exception as e:                                  # noqa: BLE001 -- a bench row must not take the line down
+        return {"error": repr(e)}
+    for line in out.splitlines():
+        mt = re.search(r"long long data\} randomized N=(\d+) .*end-to-end: ([0-9.]+) ms = ([0-9.]+) Gkeys/s \(std::stable_sort ([0-9.]+) ms\)\s+(\w+)", line)
+        if mt:
+            return {"workload": "{std::string key; long long data} randomized, radix_sort::sort(v, &Composite::key, true), end to end",
+                    "n": int(mt.group(1)), "ms": float(mt.group(2)), "gkeys_s": float(mt.group(3)),
+                    "std_stable_sort_ms": float(mt.group(4)), "matches_std_stable_sort": mt.group(5) == "OK"}
+    return {"error": "no result line", "output": out[-400:]}
 
 
 def load_traffic(name):
@@ -168,18 +277,29 @@ def main():
     ap.add_argument("--keys", dest="n", type=int, default=1 << 30, help="keys (per GPU when --gpus > 1)")
     ap.add_argument("--types", default="u32,u64")
     ap.add_argument("--shapes", default="randomized,sorted,reverse_sorted,nearly_sorted,duplicates")
+    ap.add_argument("--extra-types", default="i64,f32,f64", help="BASELINE configs[2] rows (fewer repetitions)")
+    ap.add_argument("--extra-shapes", default="randomized,duplicates")
+    ap.add_argument("--extra-steps", type=int, default=3)
+    ap.add_argument("--pairs", default="u32+4,u64+4", help="key type + payload bytes")
+    ap.add_argument("--pairs-n", type=int, default=1 << 29)
+    ap.add_argument("--strings", default="10000000", help="string counts for the rs_sort_strings rows")
+    ap.add_argument("--composite-n", type=int, default=10_000_000, help="0 = skip the configs[3] row")
     ap.add_argument("--cpu-n", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
     args.types = [t for t in args.types.split(",") if t]
     args.shapes = [s for s in args.shapes.split(",") if s]
+    args.extra_types = [t for t in args.extra_types.split(",") if t]
+    args.extra_shapes = [s for s in args.extra_shapes.split(",") if s]
+    args.pairs = [p for p in args.pairs.split(",") if p]
+    args.strings = [int(x) for x in args.strings.split(",") if x]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 or args.gpus > 1 or os.environ.get("RS_BENCH_FORCE_DIST"):
         from radix_sort_amd import dist_bench
         return dist_bench.main(args)
 
-    headline, rows, roof = bench_single(args)
+    headline, rows, roof, pair_rows, string_rows = bench_single(args)
     out = {
         "metric": "Gkeys/s (uint32/uint64, N=2^30) at 1/2/4/8 MI355X; % HBM roofline",
         "value": headline["gkeys_s"], "unit": "Gkeys/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -189,7 +309,11 @@ def main():
                                "device-resident (BASELINE configs[1]); all (type, shape) rows in `rows`"},
         "roofline": roof,
         "rows": rows,
+        "pair_rows": pair_rows,
+        "string_rows": string_rows,
     }
+    if args.composite_n:
+        out["composite_row"] = bench_composite(args.composite_n)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_n)
     print(json.dumps(out))
