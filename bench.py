@@ -250,12 +250,16 @@ def bench_composite(n):
         out = subprocess.run([exe, "1000", str(n)], capture_output=True, text=True, timeout=600).stdout
     except Exception as e:                                  # noqa: BLE001 -- a bench row must not take the line down
         return {"error": repr(e)}
+    res = {}
     for line in out.splitlines():
-        mt = re.search(r"long long data\} randomized N=(\d+) .*end-to-end: ([0-9.]+) ms = ([0-9.]+) Gkeys/s \(std::stable_sort ([0-9.]+) ms\)\s+(\w+)", line)
+        mt = re.search(r"^\{(.*)\} randomized N=(\d+) .*end-to-end: ([0-9.]+) ms = ([0-9.]+) Gkeys/s \(std::stable_sort ([0-9.]+) ms\)\s+(\w+)", line)
         if mt:
-            return {"workload": "{std::string key; long long data} randomized, radix_sort::sort(v, &Composite::key, true), end to end",
-                    "n": int(mt.group(1)), "ms": float(mt.group(2)), "gkeys_s": float(mt.group(3)),
-                    "std_stable_sort_ms": float(mt.group(4)), "matches_std_stable_sort": mt.group(5) == "OK"}
+            row = {"workload": "{" + mt.group(1) + "} randomized, radix_sort::sort(v, &T::key, true), host vectors in and out",
+                   "n": int(mt.group(2)), "ms": float(mt.group(3)), "gkeys_s": float(mt.group(4)),
+                   "std_stable_sort_ms": float(mt.group(5)), "matches_std_stable_sort": mt.group(6) == "OK"}
+            res["string_key" if "string" in mt.group(1) else "pod_int_key"] = row
+    if res:
+        return res
     return {"error": "no result line", "output": out[-400:]}
 
 

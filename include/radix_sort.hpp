@@ -14,12 +14,14 @@
 //   value path, numeric T   (:698-729)    -> rs_sort_keys, transform fused on the device
 //   value path, std::string (:528-586)    -> pack to blob+offsets, rs_sort_strings, move by permutation
 //   key path, numeric key   (:1543-1592)  -> key column + index payload, rs_sort_pairs (stable),
-//                                            then the moves of sortByIndices (:1111-1133)
+//                                            then the moves of sortByIndices (:1111-1133); trivially copyable
+//                                            objects go to the GPU with their keys and are gathered there (rs_sort_rows)
 //   key path, string key    (:1574-1578)  -> pack projected strings, rs_sort_strings (stable), moves
 // The third argument keeps its meaning for the steps that stay on the host (key column, string packing, moving the
 // objects: threaded by the reference's own rule when it is true); the device path is always parallel.
-// The reference's pre-checks (already sorted -> return, :269-305 / :746-769) and insertion-sort
-// thresholds (:42-43) change its running time, never its result, and are not reproduced.
+// The reference's pre-checks (already sorted -> return, descending -> reverse, :269-305 / :746-769) are reproduced: on the
+// device for numeric keys (rs_ctx_set_precheck), on the host for strings and projected keys (below).  Its insertion-sort
+// thresholds (:42-43) change its running time, never its result; the device's counterpart is a single-workgroup sort.
 //
 // Link with:  -L<repo>/radix-sort_amd/lib -lrsort_hip
 #pragma once
@@ -314,16 +316,31 @@ namespace radix_sort
 					device::checkKeyType<Key>();
 
 					const std::size_t threads = device::hostThreads(SIZE, enableMultiThreading);
-					std::vector<Key> k(SIZE);                 // the key column (:1581-1585)
+					// the key column (:1581-1585); a bool key is stored as a byte (std::vector<bool> has no element storage)
+					using Stored = std::conditional_t<std::same_as<Key, bool>, std::uint8_t, Key>;
+					std::vector<Stored> k(SIZE);
 					device::forRanges(SIZE, threads, [&](std::size_t lo, std::size_t hi, std::size_t) {
 						for (std::size_t i = lo; i < hi; i++)
-							k[i] = std::invoke(proj, v[i]);
+							k[i] = static_cast<Stored>(std::invoke(proj, v[i]));
 					});
 
 					rs_ctx* ctx = device::context();
 					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(threads)));
 					constexpr int XF = device::transformOf<Key>();
 					constexpr int BITS = static_cast<int>(sizeof(Key)) * 8;
+
+					// Trivially copyable objects are plain bytes: they follow their keys to the GPU and sortByIndices' random
+					// gather (:1111-1154) runs there, at HBM speed, instead of on the host (10^7 16-byte objects: the
+					// host gather alone took longer than upload, sort, gather and download together).
+					if constexpr (std::is_trivially_copyable_v<T> && sizeof(T) % 4 == 0 && sizeof(T) <= 256 && alignof(T) >= 4)
+					{
+						if (SIZE < std::numeric_limits<std::uint32_t>::max())
+						{
+							device::check(ctx, rs_sort_rows(ctx, static_cast<void*>(v.data()), SIZE, static_cast<int>(sizeof(T)),
+								k.data(), static_cast<int>(sizeof(Key)), XF));
+							return;
+						}
+					}
 
 					if (SIZE <= std::numeric_limits<std::uint32_t>::max())
 					{

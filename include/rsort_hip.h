@@ -151,6 +151,14 @@ int rs_sort_keys(rs_ctx* ctx, void* h_keys, size_t n, int key_bytes, int transfo
 int rs_sort_pairs(rs_ctx* ctx, void* h_keys, void* h_values, size_t n, int key_bytes,
                   int value_bytes, int transform, int begin_bit, int end_bit);
 
+/* rs_sort_rows: STABLE sort of n fixed-size rows (row_bytes: a multiple of 4, at most 256) by a separate key column;
+ *   h_rows is reordered in place, h_keys is only read.  Result == the projected path of the reference for trivially
+ *   copyable objects: key copy (selectProjStrategy radix_sort.hpp:1581-1585), pair sort of (key, index) (:1160-1206,
+ *   :1062-1109), then sortByIndices (:1111-1154) -- whose random gather runs on the device here: the keys go up first, the
+ *   rows follow while the pair sort runs, one kernel moves row perm[i] to place i, and only the rows come back.
+ *   n < 2^32 - 1. */
+int rs_sort_rows(rs_ctx* ctx, void* h_rows, size_t n, int row_bytes, const void* h_keys, int key_bytes, int transform);
+
 /* rs_sort_strings: order of n byte strings; string i is h_blob[h_offsets[i] .. h_offsets[i+1]).
  *   On return h_perm[i] = index of the string that belongs at position i; ascending by unsigned
  *   byte, a proper prefix first (std::string::operator<), ties in input order.

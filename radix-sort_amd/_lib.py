@@ -30,6 +30,7 @@ SYMBOLS = [
     ("rs_partition_device", _i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     ("rs_sort_keys", _i, [_vp, _vp, _sz, _i, _i, _i, _i]),
     ("rs_sort_pairs", _i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i]),
+    ("rs_sort_rows", _i, [_vp, _vp, _sz, _i, _vp, _i, _i]),
     ("rs_sort_strings", _i, [_vp, _vp, _vp, _sz, _vp, _i]),
 ]
 

@@ -580,6 +580,13 @@ int to_device(rs_ctx* c, void* d, const void* h, size_t bytes, int slot) {
   RS_HIP(c, c->mover.move(c->device, static_cast<char*>(const_cast<void*>(h)), static_cast<char*>(d), bytes, true));
   return RS_OK;
 }
+// The same for a destination that nothing queued on the stream touches: a large array moves through the lanes WHILE the
+// stream's kernels run (rs_sort_rows: the rows travel during the pair sort); a small one is queued on the stream.
+int to_device_beside_stream(rs_ctx* c, void* d, const void* h, size_t bytes, int slot) {
+  if (!staged_transfers() || bytes < rst::kStagedMin) return to_device(c, d, h, bytes, slot);
+  RS_HIP(c, c->mover.move(c->device, static_cast<char*>(const_cast<void*>(h)), static_cast<char*>(d), bytes, true));
+  return RS_OK;
+}
 // what to_host fetched into pinned memory goes to the caller's arrays (the stream has been waited for)
 void hand_over(rs_ctx* c) {
   for (int slot = 0; slot < 2; ++slot) {
@@ -923,6 +930,40 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
   return finish_host_call(c);
 }
 
+
+int rs_sort_rows(rs_ctx* c, void* h_rows, size_t n, int row_bytes, const void* h_keys, int key_bytes, int transform) {
+  int rc = check_args(c, h_keys, n, key_bytes, 4, transform, 0, key_bytes * 8);
+  if (rc != RS_OK) return rc;
+  if (row_bytes < 4 || row_bytes > 256 || (row_bytes & 3)) return fail(c, RS_ERR_ARG, "row_bytes must be a multiple of 4 between 4 and 256");
+  if (n > 0 && !h_rows) return fail(c, RS_ERR_ARG, "null row pointer");
+  if (n >= 0xFFFFFFFFull) return fail(c, RS_ERR_ARG, "rs_sort_rows takes fewer than 2^32 - 1 rows (4-byte row indices)");
+  if (n < 2) return RS_OK;
+  c->fetched[0] = c->fetched[1] = {nullptr, 0};
+  RS_HIP(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t kb = up(n * key_bytes), ib = up(n * 4), rb = up(n * static_cast<size_t>(row_bytes));
+  if ((rc = ensure(c, c->strbuf, 2 * kb + 2 * ib + 2 * rb)) != RS_OK) return rc;
+  char* p = static_cast<char*>(c->strbuf.p);
+  char* d_keys = p; char* d_keys_alt = p + kb;
+  auto* d_idx = reinterpret_cast<uint32_t*>(p + 2 * kb);
+  auto* d_idx_alt = reinterpret_cast<uint32_t*>(p + 2 * kb + ib);
+  char* d_rows = p + 2 * kb + 2 * ib; char* d_rows_out = d_rows + rb;
+  // keys up, the pair sort queued; the rows (the bulk of the bytes) travel while it runs
+  if ((rc = to_device(c, d_keys, h_keys, n * key_bytes, 0)) != RS_OK) return rc;
+  const unsigned grid = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, size_t(c->cus) * 16));
+  hipLaunchKernelGGL(rsk::iota_u32_kernel, dim3(grid), dim3(256), 0, s, d_idx, static_cast<uint64_t>(n));
+  if ((rc = sort_device(c, d_keys, d_idx, d_keys_alt, d_idx_alt, n, key_bytes, 4, transform, 0, key_bytes * 8)) != RS_OK) return rc;
+  if (c->last_unchanged) return finish_host_call(c);            // keys in order already: a stable sort moves no row
+  if ((rc = to_device_beside_stream(c, d_rows, h_rows, n * static_cast<size_t>(row_bytes), 1)) != RS_OK) return rc;
+  const unsigned words = static_cast<unsigned>(row_bytes / 4);
+  const unsigned ggrid = static_cast<unsigned>(std::min<size_t>((n * words + 255) / 256, size_t(c->cus) * 32));
+  hipLaunchKernelGGL(rsk::gather_rows_kernel, dim3(ggrid), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(d_rows), d_idx,
+                     reinterpret_cast<uint32_t*>(d_rows_out), static_cast<uint64_t>(n), words);
+  RS_HIP(c, hipGetLastError());
+  if ((rc = to_host(c, h_rows, d_rows_out, n * static_cast<size_t>(row_bytes), 0)) != RS_OK) return rc;
+  return finish_host_call(c);
+}
 
 int rs_digit_histogram_device(rs_ctx* c, const void* d_keys, size_t n, int key_bytes, int transform, int begin_bit,
                               int end_bit, uint64_t* h_counts) {

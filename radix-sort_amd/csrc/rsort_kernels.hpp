@@ -1013,6 +1013,26 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 
 
 // ------------------------------------------------------------------------------------------------
+// 3b. permutation gather of fixed-size rows (sortByIndices, radix_sort.hpp:1111-1154, for trivially copyable objects)
+// ------------------------------------------------------------------------------------------------
+// out row i = in row perm[i]; rows are `words` 32-bit words long.  Thread per word: the lanes that share a row read
+// consecutive words of it, rows land at random (one 32..256-byte piece per row), writes are contiguous.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t* in, const uint32_t* perm, uint32_t* out,
+                                                          uint64_t n, unsigned words) {
+  const uint64_t total = n * words;
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const uint64_t row = i / words;
+    const unsigned w = static_cast<unsigned>(i - row * words);
+    out[i] = in[static_cast<uint64_t>(perm[row]) * words + w];
+  }
+}
+__global__ __launch_bounds__(256) void iota_u32_kernel(uint32_t* a, uint64_t n) {
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = static_cast<uint32_t>(i);
+}
+
+// ------------------------------------------------------------------------------------------------
 // 4. small inputs: the whole sort in one workgroup
 // ------------------------------------------------------------------------------------------------
 // n <= one tile.  One launch does every pass: keys (and payload) stay in registers / LDS between passes, there is no

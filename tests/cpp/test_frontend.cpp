@@ -84,6 +84,39 @@ template <class K> static void check_key(const char* name, size_t n, int shape) 
   if (!ok) { ++failures; std::printf("WRONG SORT key %s n=%zu shape=%d\n", name, n, shape); }
 }
 
+// Trivially copyable objects wider than 8 bytes: the front-end sends them to the GPU with their keys and the permutation is
+// applied there (rs_sort_rows); the result must still be the stable order, payload for payload.
+template <class K> struct Pod { K key; unsigned seq; long long data; };
+template <class K> static void check_pod(const char* name, size_t n, int shape) {
+  static_assert(std::is_trivially_copyable_v<Pod<K>> && sizeof(Pod<K>) % 4 == 0);
+  std::mt19937_64 gen(2069 + n + shape);
+  std::vector<K> keys = make_keys<K>(n, shape, gen);
+  std::vector<Pod<K>> v(n);
+  for (size_t i = 0; i < n; i++) v[i] = {keys[i], static_cast<unsigned>(i), static_cast<long long>(i) * 3 - 7};
+  auto want = v;
+  std::stable_sort(want.begin(), want.end(), [](const auto& a, const auto& b) { return total_less(a.key, b.key); });
+  radix_sort::sort(v, &Pod<K>::key, shape % 2 == 0);
+  bool ok = true;
+  for (size_t i = 0; ok && i < n; i++) ok = same_bits(v[i].key, want[i].key) && v[i].seq == want[i].seq && v[i].data == want[i].data;
+  ++cases;
+  if (!ok) { ++failures; std::printf("WRONG SORT pod %s n=%zu shape=%d\n", name, n, shape); }
+}
+
+// A projection that returns bool (std::integral, so `supported`): two buckets, stable inside each.
+static void check_bool_projection(size_t n) {
+  struct Flagged { bool flag; std::string tag; long long data; };
+  std::mt19937_64 gen(3069 + n);
+  std::vector<Flagged> v(n);
+  for (size_t i = 0; i < n; i++) v[i] = {static_cast<bool>(gen() & 1), "f" + std::to_string(i % 5), static_cast<long long>(i)};
+  auto want = v;
+  std::stable_sort(want.begin(), want.end(), [](const Flagged& a, const Flagged& b) { return a.flag < b.flag; });
+  radix_sort::sort(v, &Flagged::flag, true);
+  bool ok = true;
+  for (size_t i = 0; ok && i < n; i++) ok = v[i].flag == want[i].flag && v[i].data == want[i].data && v[i].tag == want[i].tag;
+  ++cases;
+  if (!ok) { ++failures; std::printf("WRONG SORT bool projection n=%zu\n", n); }
+}
+
 int main() {
   const size_t sizes[] = {0, 1, 2, 10, 100, 101, 1000, 10000, 100000, 1000000};
   for (size_t n : sizes)
@@ -107,7 +140,13 @@ int main() {
         check_key<unsigned char>("complex_u8", n, shape);
         check_key<std::string>("complex_str", n, shape);
       }
+      check_pod<int>("pod_i32", n, shape);
+      check_pod<double>("pod_double", n, shape);
+      check_pod<unsigned short>("pod_u16", n, shape);
     }
+  check_pod<long long>("pod_ll_threaded", 2100001, 0);
+  check_pod<float>("pod_float_sorted", 100000, 3);
+  for (size_t n : {size_t(2), size_t(1000), size_t(300000)}) check_bool_projection(n);
   // above 2,000,000 elements with the third argument true the host-side steps (key column, string packing, moving
   // the objects) run on several threads, by the reference's own rule (getNumOfThreads, radix_sort.hpp:112-123)
   check_key<int>("complex_i32_threaded", 2100001, 0);
