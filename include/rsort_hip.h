@@ -108,7 +108,7 @@ int rs_sort_keys_device(rs_ctx* ctx, void* d_keys, void* d_alt, size_t n, int ke
  *   kernels are queued on the context's stream and the call returns.  Consequently: d_alt (n*key_bytes bytes) is
  *   required; there is no order pre-check and no pass skipping (both need counts on the host); n <= RS_NOALLOC_MAX_KEYS,
  *   larger n is rejected with RS_ERR_ARG.  Histograms, tickets and look-back descriptors live in a static device array of
- *   4.06 MiB that every GPU the library runs on holds until the process ends.  All calls on one GPU share that array:
+ *   4.5 MiB that every GPU the library runs on holds until the process ends.  All calls on one GPU share that array:
  *   calls that overlap on one GPU (two streams, two contexts, two threads) race and must be serialised by the caller;
  *   each call clears what it needs at its start.  A fault is reported by the next rs_ctx_synchronize, as for the other
  *   device entry points. */

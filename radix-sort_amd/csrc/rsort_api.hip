@@ -20,7 +20,7 @@
 #include "rsort_strings.hpp"
 
 // see Workspace below; named only in rs_ctx_create (hipGetSymbolAddress), everything else uses the address kept in the context
-static __device__ __align__(256) unsigned char rs_static_scratch[(size_t(1) << 22) + 65536];
+static __device__ __align__(256) unsigned char rs_static_scratch[(size_t(1) << 22) + (size_t(1) << 19)];
 
 namespace {
 
@@ -80,7 +80,7 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // where it pays -- sorts of at least this many tiles (16 M four-byte keys), which saturate the GPU on their own -- and
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
-constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) pass skipping is not worth its host synchronisation
+constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) neither pass skipping nor the order pre-check is worth a host synchronisation
 
 struct DevBuf {
   void* p = nullptr;
@@ -94,14 +94,15 @@ struct rs_ctx {
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
   DevBuf alt_keys, alt_vals, desc, ctrl, strbuf;
-  // ctrl layout (kCtrl* below): [0, 16K) ghist u64[8][256]; [16K, 32K) gbase u64[8][256]; then per pass one ticket word
-  //              per XCD, a cache line apart (8 x kTicketWords u32); then 64 bytes: error word at +0, order-check flags at +32
+  // ctrl layout: kCtrl* below
   bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
   bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create (and cleared by rs_ctx_set_tile_order)
   bool per_xcd_probe_ok = false;     // what the probe found
   int cus = 256;                     // compute units of the device (persistent grids: 2 workgroups each)
   char* static_scratch = nullptr;    // this device's copy of rs_static_scratch (rs_sort_keys_device_noalloc)
   bool static_used = false;          // a sort has used it since its error word was last read
+  unsigned* pinned_flags = nullptr;  // two pinned host words the error words are fetched into (a pageable 4-byte copy costs 20 us)
+  bool host_call = false;            // sort_device runs inside a host-buffer entry point (which waits for the device anyway)
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   bool last_unchanged = false;   // the last sort_device found its input already in order and moved nothing
@@ -114,11 +115,17 @@ struct rs_ctx {
 
 namespace {
 
-constexpr size_t kCtrlHist = 0;
-constexpr size_t kCtrlBase = kMaxPasses * 256 * 8;
-constexpr size_t kCtrlTicket = 2 * kCtrlBase;
-constexpr size_t kCtrlError = kCtrlTicket + kMaxPasses * rsk::kTicketWords * sizeof(unsigned);   // per pass: one ticket word per XCD, a cache line apart
-constexpr size_t kCtrlBytes = kCtrlError + 64;   // error word at +0, order-check flags at +32
+// Control block: [0, 64) error word (+0) and order-check flags (+32), never part of a per-sort memset; then what every
+// sort clears with ONE memset: digit counts u64[8][256], their exclusive prefixes u64[8][256], per pass one ticket word per
+// XCD a cache line apart, and -- directly behind, so that the same memset reaches them -- the look-back descriptors of
+// sorts of at most kAlwaysSweepTiles tiles (256 KB); larger sorts use the separate descriptor buffer.
+constexpr size_t kCtrlError = 0;
+constexpr size_t kCtrlHist = 64;
+constexpr size_t kCtrlBase = kCtrlHist + kMaxPasses * 256 * 8;
+constexpr size_t kCtrlTicket = kCtrlBase + kMaxPasses * 256 * 8;
+constexpr size_t kCtrlMidDesc = kCtrlTicket + kMaxPasses * rsk::kTicketWords * sizeof(unsigned);
+constexpr size_t kMidDescTiles = 256;
+constexpr size_t kCtrlBytes = kCtrlMidDesc + kMidDescTiles * 256 * 4;
 // chain mode only (rsort_kernels.hpp, "XCD chains"), zeroed only by sorts that use it:
 constexpr size_t kCtrlChainHist = (kCtrlBytes + 255) & ~size_t(255);                       // u64 [8 chains][8 passes][256] from the histogram kernel
 constexpr size_t kCtrlNextCnt = kCtrlChainHist + rsk::kXcds * rsk::kChainHistStride * 8;   // u64 [8 passes][8 chains][256] from the sweeps
@@ -130,10 +137,16 @@ constexpr size_t kCtrlBytesChain = kCtrlNextCnt + kMaxPasses * rsk::kXcds * 256 
 constexpr size_t kNoAllocMaxKeys = size_t(1) << 25;
 constexpr size_t kNoAllocCtrlBytes = (kCtrlBytes + 255) & ~size_t(255);
 constexpr size_t kNoAllocDescBytes = (kNoAllocMaxKeys / 8192) * 256 * 4;     // smallest tile of any geometry, 4-byte descriptors
-constexpr size_t kNoAllocBytes = kNoAllocCtrlBytes + kNoAllocDescBytes;       // 4.02 MiB
+constexpr size_t kNoAllocBytes = kNoAllocCtrlBytes + kNoAllocDescBytes;       // 4.3 MiB (the array is declared with 4.5 MiB)
 struct Workspace {        // non-null: sort_device uses these and neither allocates nor waits for the device
   char* ctrl;
   void* desc;
+};
+
+struct HostCall {         // marks the context for the duration of a host-buffer entry point
+  rs_ctx* c;
+  explicit HostCall(rs_ctx* ctx) : c(ctx) { c->host_call = true; }
+  ~HostCall() { c->host_call = false; }
 };
 
 int fail(rs_ctx* c, int code, const std::string& msg) {
@@ -357,10 +370,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     return RS_OK;
   }
 
+  // Mid-size sorts (at most kAlwaysSweepTiles tiles) keep their descriptors inside the control block: one memset, no
+  // descriptor buffer, and -- below -- no host synchronisation at all.
+  const bool mid = tiles <= kAlwaysSweepTiles && !wide;
   int rc;
   if (!ws) {
     if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
-    if ((rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
+    if (!mid && (rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
   } else {
     c->static_used = true;
   }
@@ -374,7 +390,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   }
 
   char* ctrl = ws ? ws->ctrl : static_cast<char*>(c->ctrl.p);
-  void* const desc = ws ? ws->desc : c->desc.p;
+  void* const desc = mid ? static_cast<void*>(ctrl + kCtrlMidDesc) : ws ? ws->desc : c->desc.p;
   auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);
   auto* gbase = reinterpret_cast<unsigned long long*>(ctrl + kCtrlBase);
   auto* tickets = reinterpret_cast<unsigned*>(ctrl + kCtrlTicket);
@@ -382,7 +398,9 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
 
   // Order pre-check (isSortedBi :269-305 / key::isSorted :746-769): ascending on the sorted field -> nothing to do
   // (a stable sort of ordered input is the identity); descending, whole key, no payload -> reverse in place.
-  if (c->precheck && !ws) {
+  // Not for mid-size device-resident sorts: there the two launches and the read-back cost as much as the sort
+  // (the host-buffer entry points, which wait for the device anyway and save a download when the input is in order, ask for it).
+  if (c->precheck && !ws && (!mid || c->host_call)) {
     rsk::OrderArgs o{};
     o.keys = keys; o.flags = error_flag + 8; o.n = n; o.fmask = fmask; o.smask = smask;
     o.begin_bit = begin_bit; o.bits = end_bit - begin_bit;
@@ -440,9 +458,9 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   int ev = 0;
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
   // counts, bases and tickets; NOT the error word behind them: it keeps a fault until check_kernel_error has read it
-  RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlError, s));
+  RS_HIP(c, hipMemsetAsync(ctrl + kCtrlHist, 0, kCtrlMidDesc - kCtrlHist + (mid ? tiles * 256 * 4 : 0), s));
   if (chain) RS_HIP(c, hipMemsetAsync(ctrl + kCtrlChainHist, 0, kCtrlBytesChain - kCtrlChainHist, s));
-  RS_HIP(c, hipMemsetAsync(desc, 0, tiles * 256 * (wide ? 8 : 4), s));   // the rows this sort uses, not the whole reservation
+  if (!mid) RS_HIP(c, hipMemsetAsync(desc, 0, tiles * 256 * (wide ? 8 : 4), s));   // the rows this sort uses, not the whole reservation
 
   auto* chain_hist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlChainHist);
   auto* next_cnt = reinterpret_cast<unsigned long long*>(ctrl + kCtrlNextCnt);
@@ -464,7 +482,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   int live[kMaxPasses];     // the passes that are launched, in order
   int n_live = 0;
   int min_bins = 256;       // fewest digit values in use over the launched passes (known only with the counts on the host)
-  if (ws || (tiles <= kAlwaysSweepTiles && passes <= 4)) {
+  if (ws || mid) {
     for (int p = 0; p < passes; ++p) live[n_live++] = p;
   } else {
     unsigned long long h_hist[kMaxPasses * 256];
@@ -538,11 +556,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
 // the word is not part of the per-sort memset and kernels only OR into it, so a fault is neither lost to a later sort
 // nor reported twice.
 int check_kernel_error(rs_ctx* c) {
-  unsigned flag = 0, sflag = 0;
   char* ctrl = static_cast<char*>(c->ctrl.p);
-  if (ctrl) RS_HIP(c, hipMemcpyAsync(&flag, ctrl + kCtrlError, sizeof(flag), hipMemcpyDeviceToHost, c->stream));
-  if (c->static_used) RS_HIP(c, hipMemcpyAsync(&sflag, c->static_scratch + kCtrlError, sizeof(sflag), hipMemcpyDeviceToHost, c->stream));
+  unsigned* f = c->pinned_flags;
+  f[0] = f[1] = 0;
+  if (ctrl) RS_HIP(c, hipMemcpyAsync(&f[0], ctrl + kCtrlError, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  if (c->static_used) RS_HIP(c, hipMemcpyAsync(&f[1], c->static_scratch + kCtrlError, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   RS_HIP(c, hipStreamSynchronize(c->stream));      // (also the wait when only single-workgroup sorts ran: no error word yet)
+  unsigned flag = f[0], sflag = f[1];
   c->static_used = false;
   if (flag) RS_HIP(c, hipMemsetAsync(ctrl + kCtrlError, 0, sizeof(flag), c->stream));
   if (sflag) RS_HIP(c, hipMemsetAsync(c->static_scratch + kCtrlError, 0, sizeof(sflag), c->stream));
@@ -666,6 +686,11 @@ int rs_ctx_create(rs_ctx** out, int device) {
   }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { rs_ctx_destroy(c); return RS_ERR_HIP; }
+  if (hipHostMalloc(reinterpret_cast<void**>(&c->pinned_flags), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+    c->pinned_flags = nullptr;
+    rs_ctx_destroy(c);
+    return RS_ERR_HIP;
+  }
   // this device's copy of the static workspace (the array's name is only a host-side handle: kernels and memsets get
   // the address looked up here, with the device current)
   static_assert(sizeof(rs_static_scratch) >= kNoAllocBytes, "static workspace too small");
@@ -726,6 +751,7 @@ int rs_ctx_destroy(rs_ctx* c) {
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   c->mover.release_all();
+  if (c->pinned_flags) (void)hipHostFree(c->pinned_flags);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return RS_OK;
@@ -853,7 +879,7 @@ int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, cons
   const uint64_t fmask = transform == RS_XF_IEEE ? all : 0;
   const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
 
-  RS_HIP(c, hipMemsetAsync(ctrl, 0, kCtrlError, s));       // (not the error word: see sort_device)
+  RS_HIP(c, hipMemsetAsync(ctrl + kCtrlHist, 0, kCtrlMidDesc - kCtrlHist, s));       // (not the error word: see sort_device)
   RS_HIP(c, hipMemsetAsync(c->desc.p, 0, tiles * 256 * (wide ? 8 : 4), s));
   rsk::HistArgs h{};
   h.keys = d_keys_in; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
@@ -889,6 +915,7 @@ int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, cons
 int rs_sort_keys(rs_ctx* c, void* h_keys, size_t n, int key_bytes, int transform, int begin_bit, int end_bit) {
   int rc = check_args(c, h_keys, n, key_bytes, 0, transform, begin_bit, end_bit);
   if (rc != RS_OK) return rc;
+  HostCall host_call(c);
   if (n < 2) return RS_OK;
   c->fetched[0] = c->fetched[1] = {nullptr, 0};   // nothing left over from a call that failed half-way
   RS_HIP(c, hipSetDevice(c->device));
@@ -908,6 +935,7 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
                   int begin_bit, int end_bit) {
   int rc = check_args(c, h_keys, n, key_bytes, value_bytes, transform, begin_bit, end_bit);
   if (rc != RS_OK) return rc;
+  HostCall host_call(c);
   if (value_bytes == 0) return fail(c, RS_ERR_ARG, "value_bytes must be 4 or 8");
   if (n > 0 && !h_values) return fail(c, RS_ERR_ARG, "null value pointer");
   if (n < 2) return RS_OK;
@@ -934,6 +962,7 @@ int rs_sort_pairs(rs_ctx* c, void* h_keys, void* h_values, size_t n, int key_byt
 int rs_sort_rows(rs_ctx* c, void* h_rows, size_t n, int row_bytes, const void* h_keys, int key_bytes, int transform) {
   int rc = check_args(c, h_keys, n, key_bytes, 4, transform, 0, key_bytes * 8);
   if (rc != RS_OK) return rc;
+  HostCall host_call(c);
   if (row_bytes < 4 || row_bytes > 256 || (row_bytes & 3)) return fail(c, RS_ERR_ARG, "row_bytes must be a multiple of 4 between 4 and 256");
   if (n > 0 && !h_rows) return fail(c, RS_ERR_ARG, "null row pointer");
   if (n >= 0xFFFFFFFFull) return fail(c, RS_ERR_ARG, "rs_sort_rows takes fewer than 2^32 - 1 rows (4-byte row indices)");
