@@ -20,7 +20,15 @@ HipLocal (C-ABI on the rank's GPU).  tests/ plug in a numpy backend to exercise 
 and the exchange on CPU with gloo -- the product path never does.
 
 Balance: split points fall on 16-bit prefixes, so a rank can exceed N/G by at most the largest
-16-bit bucket.  Keys-only sorts could split a bucket of EQUAL keys by count as well; not done yet.
+16-bit bucket -- unless that bucket holds ONE key value on every rank (few-valued inputs: the
+reference's "duplicates" shape puts N/256 equal keys into a bucket).  Such a bucket is cut by count
+at the exact quantile: each rank checks its part (all remaining digits constant), one more small
+all-gather compares the values, and the cut takes the bucket's keys in (source rank, position)
+order, so equal keys keep their global input order and the payload variant stays stable.
+
+`stats` (a dict) makes distributed_sort record per-phase wall times (with a device synchronisation
+at each phase end, so only for diagnosis) and the bytes this rank sent; dist_bench.py runs one such
+sort after the timed ones.
 """
 from __future__ import annotations
 
@@ -93,14 +101,49 @@ def count_below(level1: np.ndarray, level2: dict, x16: int) -> int:
     return n
 
 
-def exchange_counts(level1_all, level2_all, split16, world):
-    """counts[i][r] = keys rank i sends to rank r."""
-    counts = np.zeros((world, world), dtype=np.int64)
+def exchange_counts(level1_all, level2_all, split16, world, inner_cuts=None):
+    """counts[i][r] = keys rank i sends to rank r.
+
+    inner_cuts: {r: (x16, extra)} -- boundary r lies INSIDE the 16-bit bucket x16, whose keys are all equal: the first
+    `extra` of them, counted over the sources in rank order, go below the boundary (split16[r] == x16 for those r)."""
+    inner_cuts = inner_cuts or {}
+    below = np.zeros((world, world + 1), dtype=np.int64)
     for i in range(world):
         l2 = {b: t[i] for b, t in level2_all.items()}
-        below = [count_below(level1_all[i], l2, int(split16[r])) for r in range(world + 1)]
-        counts[i] = np.diff(below)
-    return counts
+        below[i] = [count_below(level1_all[i], l2, int(split16[r])) for r in range(world + 1)]
+    for r, (x16, extra) in inner_cuts.items():
+        per_source = bucket_counts(level1_all, level2_all, x16)            # [G] keys of the bucket on each source
+        before = np.concatenate(([0], np.cumsum(per_source)[:-1]))          # ... on the sources in front of it
+        below[:, r] += np.clip(extra - before, 0, per_source)
+    below = np.maximum.accumulate(below, axis=1)
+    return np.diff(below, axis=1)
+
+
+def bucket_counts(level1_all, level2_all, x16):
+    """[G] keys with 16-bit prefix x16 on every rank (x16 on a top-digit edge of an unrefined bucket = that whole bucket)."""
+    b, s2 = x16 >> 8, x16 & 255
+    if b in level2_all:
+        return level2_all[b][:, s2].astype(np.int64)
+    return level1_all[:, b].astype(np.int64)
+
+
+def quantile_bucket(level1_all, level2_all, q, two_levels):
+    """(x16, keys in front of the bucket, keys in it) for the 16-bit bucket that holds global position q, or None when
+    the tables do not resolve it (its top-digit bucket was not refined although the keys have a second digit)."""
+    g1 = level1_all.sum(axis=0).astype(np.int64)
+    cum1 = np.cumsum(g1)
+    b = int(np.searchsorted(cum1, q, side="right"))
+    if b >= 256:
+        return None
+    base = int(cum1[b] - g1[b])
+    if not two_levels:
+        return (b << 8), base, int(g1[b])
+    if b not in level2_all:
+        return None
+    g2 = level2_all[b].sum(axis=0).astype(np.int64)
+    cum2 = base + np.cumsum(g2)
+    s2 = min(int(np.searchsorted(cum2, q, side="right")), 255)
+    return (b << 8) + s2, int(cum2[s2] - g2[s2]), int(g2[s2])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -198,6 +241,22 @@ class HipLocal:
             vs = vscratch.data_ptr() if vscratch is not None and vscratch.numel() >= n else None
             self.eng.sort_pairs_ptr(t.data_ptr(), vals.data_ptr(), n, self.kb, vals.element_size(), self.xf, ks, vs)
 
+    def single_value(self, t, lo, hi, below_bit):
+        """(1, v) when every key of t[lo:hi] has the same transformed bits below `below_bit` (v = those bits), (0, 0) for an
+        empty range, (2, 0) otherwise: one histogram of the remaining digits, each with exactly one bin in use."""
+        if hi <= lo:
+            return 0, 0
+        if below_bit <= 0:
+            return 1, 0
+        h = self.eng.digit_histogram_ptr(t.data_ptr() + lo * self.kb, hi - lo, self.kb, self.xf, 0, below_bit)
+        v = 0
+        for p in range(h.shape[0]):
+            nz = np.flatnonzero(h[p])
+            if nz.size != 1:
+                return 2, 0
+            v |= int(nz[0]) << (8 * p)
+        return 1, v
+
     def synchronize(self):
         self.eng.synchronize()
 
@@ -213,23 +272,40 @@ class HipLocal:
 # ---------------------------------------------------------------------------------------------
 # the distributed sort
 # ---------------------------------------------------------------------------------------------
-def distributed_sort(keys, local, comm: Comm, values=None):
+def distributed_sort(keys, local, comm: Comm, values=None, stats=None):
     """keys: this rank's 1-D tensor of raw key bits (int32 / int64 ...).  Returns this rank's slice of
     the globally sorted sequence (a new tensor); `keys` (and `values`) are used as scratch and are clobbered.
 
     values: optional 1-D payload tensor (4- or 8-byte elements) that travels with the keys; the result is then
     (keys, values) and the sort is STABLE over the concatenation of the ranks' inputs in rank order -- equal keys keep
-    (source rank, position) order: every partition pass is stable, a 16-bit split never separates equal keys, the
-    exchange delivers the sources' pieces in rank order and the final local sort is stable.  With values = global
-    indices this is the permutation the reference's projected sort applies (radix_sort.hpp:1111-1154)."""
+    (source rank, position) order: every partition pass is stable, a 16-bit split never separates equal keys unless
+    the whole bucket is one value (then the cut follows (source rank, position) order), the exchange delivers the
+    sources' pieces in rank order and the final local sort is stable.  With values = global indices this is the
+    permutation the reference's projected sort applies (radix_sort.hpp:1111-1154).
+
+    stats: optional dict; receives {"phase_ms": {...}, "bytes_sent": ..., "keys_received": ...} (adds a device
+    synchronisation at the end of every phase)."""
+    import time
     world = comm.world
     n = keys.numel()
+    clock = [time.perf_counter()]
+    phase_ms = {}
+
+    def phase(name):
+        if stats is not None:
+            local.synchronize()
+            local.wait_for_producers(keys)
+            now = time.perf_counter()
+            phase_ms[name] = phase_ms.get(name, 0.0) + (now - clock[0]) * 1e3
+            clock[0] = now
+
     local.wait_for_producers(keys)
     if world == 1:
         local.sort(keys, None, values, None)
         local.synchronize()
         return keys if values is None else (keys, values)
     top = local.top
+    two_levels = top >= 2 * DIGIT
     scratch = local.empty_like(keys, n)
     vscratch = local.empty_like(values, n) if values is not None else None
 
@@ -239,25 +315,69 @@ def distributed_sort(keys, local, comm: Comm, values=None):
     keys, scratch = scratch, keys
     if values is not None:
         values, vscratch = vscratch, values
+    phase("partition_top_digit")
 
     # 2. the counts, all-gathered
     level1_all = comm.all_gather_table(h1, keys.device)                    # [G, 256]
+    phase("gather_tables")
 
     # 3. refine the buckets that hold a quantile; 4b. partition those buckets on the second digit
-    refine = boundary_buckets(level1_all, world) if top >= 2 * DIGIT else []
+    refine = boundary_buckets(level1_all, world) if two_levels else []
     level2_all = {}
+    offs = np.concatenate(([0], np.cumsum(h1)))
+    mine = np.zeros((len(refine), 256), dtype=np.int64)
     if refine:
-        offs = np.concatenate(([0], np.cumsum(h1)))
-        mine = np.zeros((len(refine), 256), dtype=np.int64)
         for k, b in enumerate(refine):
             lo, hi = int(offs[b]), int(offs[b + 1])
             mine[k] = local.histogram(keys, lo, hi, top - 2 * DIGIT, top - DIGIT)
             local.partition(keys, lo, hi, top - 2 * DIGIT, top - DIGIT, scratch, values, vscratch)
+        phase("refine_second_digit")
         gathered = comm.all_gather_table(mine, keys.device)                # [G, len(refine), 256]
         for k, b in enumerate(refine):
             level2_all[b] = gathered[:, k, :]
+        phase("gather_tables")
     split16 = plan_splits(level1_all, level2_all, world)
-    counts = exchange_counts(level1_all, level2_all, split16, world)
+
+    # 3b. a boundary that the 16-bit resolution leaves far from its quantile: if the bucket holding the quantile is ONE key
+    # value on every rank, it is cut by count (module docstring)
+    total = int(level1_all.sum())
+    tolerance = max(64, total // world // 200)
+    candidates = {}                                                         # r -> (x16, keys in front, keys in the bucket)
+    for r in range(1, world):
+        q = (r * total) // world
+        reached = sum(count_below(level1_all[i], {b: t[i] for b, t in level2_all.items()}, int(split16[r])) for i in range(world))
+        if abs(reached - q) > tolerance:
+            hit = quantile_bucket(level1_all, level2_all, q, two_levels)
+            if hit is not None and hit[1] < q < hit[1] + hit[2]:
+                candidates[r] = hit
+    inner_cuts = {}
+    if candidates:
+        buckets = sorted({hit[0] for hit in candidates.values()})
+        below_bit = top - 2 * DIGIT if two_levels else top - DIGIT
+        report = np.zeros((len(buckets), 2), dtype=np.int64)
+        for k, x16 in enumerate(buckets):
+            b, s2 = x16 >> 8, x16 & 255
+            lo = int(offs[b])
+            if two_levels:
+                row = mine[refine.index(b)]
+                lo += int(row[:s2].sum())
+                hi = lo + int(row[s2])
+            else:
+                hi = int(offs[b + 1])
+            flag, v = local.single_value(keys, lo, hi, below_bit)
+            report[k] = (flag, v)                                           # v < 2^48: at most the digits below the 16-bit prefix
+        reports = comm.all_gather_table(report, keys.device)                # [G, buckets, 2]
+        for r, (x16, front, _) in candidates.items():
+            rep = reports[:, buckets.index(x16), :]
+            held = rep[rep[:, 0] != 0]
+            if held.size and np.all(held[:, 0] == 1) and np.all(held[:, 1] == held[0, 1]):
+                inner_cuts[r] = (x16, (r * total) // world - front)
+                split16[r] = x16
+        for r in range(1, world + 1):
+            split16[r] = max(split16[r], split16[r - 1])
+        inner_cuts = {r: cut for r, cut in inner_cuts.items() if split16[r] == cut[0]}
+        phase("equal_key_buckets")
+    counts = exchange_counts(level1_all, level2_all, split16, world, inner_cuts)
     send_counts, recv_counts = counts[comm.rank], counts[:, comm.rank]
 
     # 5. exchange
@@ -268,9 +388,18 @@ def distributed_sort(keys, local, comm: Comm, values=None):
     if values is not None:
         vrecv = local.empty_like(values, int(recv_counts.sum()))
         comm.all_to_all(values, send_counts, recv_counts, vrecv)
+    if stats is not None:
+        local.wait_for_producers(recv)
+    phase("exchange")
 
     # 6. local LSD sort of the received range (once the exchange has delivered it)
     local.wait_for_producers(recv)
     local.sort(recv, scratch, vrecv, vscratch)
     local.synchronize()
+    phase("local_sort")
+    if stats is not None:
+        elem = keys.element_size() + (values.element_size() if values is not None else 0)
+        stats["phase_ms"] = phase_ms
+        stats["bytes_sent"] = int((send_counts.sum() - send_counts[comm.rank]) * elem)
+        stats["keys_received"] = int(recv_counts.sum())
     return recv if values is None else (recv, vrecv)

@@ -91,6 +91,21 @@ def _run_type(args, name, rank, world, dev):
         if it >= args.warmup:
             times.append(t1 - t0)
             pass_ms.extend(eng.profile()[1:])
+    # one more sort, outside the timed steps, with per-phase clocks (a device synchronisation at every phase end)
+    work.copy_(src)
+    del out
+    torch.cuda.synchronize()
+    dist.barrier()
+    st = {}
+    out = rsd.distributed_sort(work, local, comm, stats=st)
+    torch.cuda.synchronize()
+    names = ["partition_top_digit", "gather_tables", "refine_second_digit", "equal_key_buckets", "exchange", "local_sort"]
+    ph = torch.tensor([st["phase_ms"].get(k, 0.0) for k in names] + [float(st["bytes_sent"])], dtype=torch.float64, device=cdev)
+    ph_max = ph.clone()
+    dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
+    dist.all_reduce(ph, op=dist.ReduceOp.SUM)
+    phase_ms = {k: round(float(ph_max[i].item()), 3) for i, k in enumerate(names)}
+    bytes_sent_total = int(ph[len(names)].item())
     tsum = torch.tensor([sum(times)], dtype=torch.float64, device=cdev)     # max over ranks of the K timed steps
     dist.all_reduce(tsum, op=dist.ReduceOp.MAX)
     sec = float(tsum.item()) / len(times)
@@ -118,6 +133,9 @@ def _run_type(args, name, rank, world, dev):
            "parity": {"locally_sorted_all_ranks": s[4] == world, "rank_edges_ordered": ok_edges,
                       "count_kept": s[0] == s[2], "checksum_kept": s[1] == s[3]},
            "keys_per_rank_after_exchange": sizes.cpu().tolist(),
+           "phase_ms_max_over_ranks": phase_ms,          # from the extra, synchronised sort: where a step's time goes
+           "bytes_sent_all_ranks": bytes_sent_total,
+           "exchange_gbs_per_rank": (bytes_sent_total / world / (phase_ms["exchange"] * 1e-3) / 1e9) if phase_ms["exchange"] > 0 else None,
            "roofline": {"bound": "hbm", "kernel": f"onesweep_kernel<{name}> (local sort, rank 0)", "achieved": achieved,
                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None}}
     del out, work, src

@@ -62,6 +62,14 @@ class NumpyLocal:
             v[:] = v[perm.astype(np.int64)]
             a[:] = k.view(a.dtype)
 
+    def single_value(self, t, lo, hi, below_bit):
+        if hi <= lo:
+            return 0, 0
+        if below_bit <= 0:
+            return 1, 0
+        low = self._order_bits(t.numpy()[lo:hi]).astype(np.uint64) & np.uint64((1 << below_bit) - 1)
+        return (1, int(low[0])) if bool((low == low[0]).all()) else (2, 0)
+
     def synchronize(self):
         pass
 

@@ -123,3 +123,49 @@ def test_distributed_pairs_are_stable_gloo(tmp_path, oracle, world, name, shape)
     wk, wp = oracle.sort_pairs(full, xf, mt=True)
     assert gk.tobytes() == wk.tobytes()
     assert np.array_equal(gv.astype(np.uint64), wp.astype(np.uint64))
+
+
+@pytest.mark.parametrize("shape", ["randomized", "sorted", "reverse_sorted", "nearly_sorted", "duplicates"])
+def test_world8_all_shapes_sorted_and_balanced(tmp_path, oracle, shape):
+    """BASELINE configs[4] rehearsed on CPU: 8 ranks, uint64 keys, every generator shape -- the exact global order, and
+    after the exchange no rank holds much more than its share (the 256-value duplicates shape included: buckets of equal
+    keys are cut by count)."""
+    world, n_per_rank = 8, 12_000
+    mp.spawn(_worker, args=(world, _free_port(), "u64", shape, n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    full = shapes.generate("u64", n_per_rank * world + 17, shape)
+    outs = [np.load(tmp_path / f"out{r}.npy") for r in range(world)]
+    assert np.concatenate(outs).tobytes() == oracle.sort_keys(full, 0, mt=True).tobytes()
+    sizes = np.array([o.size for o in outs], dtype=np.float64)
+    assert sizes.max() / sizes.mean() <= (1.3 if shape == "duplicates" else 1.05), sizes
+
+
+def test_world8_stable_pairs_on_duplicates(tmp_path, oracle):
+    """Equal-key buckets cut by count must keep the global input order of the equal keys (payload = global position)."""
+    world, n_per_rank = 8, 6_000
+    mp.spawn(_pair_worker, args=(world, _free_port(), "u32", "duplicates", n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    full = shapes.generate("u32", n_per_rank * world + 17, "duplicates")
+    gk = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
+    gv = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)])
+    wk, wp = oracle.sort_pairs(full, 0, mt=True)
+    assert gk.tobytes() == wk.tobytes()
+    assert np.array_equal(gv.astype(np.uint64), wp.astype(np.uint64))
+    sizes = np.array([np.load(tmp_path / f"k{r}.npy").size for r in range(world)], dtype=np.float64)
+    assert sizes.max() / sizes.mean() <= 1.3, sizes
+
+
+def test_equal_key_bucket_is_cut_by_count():
+    """Planning only: every key equal (one 16-bit bucket holds everything) -- the inner cuts give each rank its share, taken
+    from the sources in rank order."""
+    world = 4
+    l1 = np.zeros((world, 256), dtype=np.int64)
+    l1[:, 9] = [1000, 10, 500, 490]
+    l2 = {9: np.zeros((world, 256), dtype=np.int64)}
+    l2[9][:, 200] = l1[:, 9]
+    x16 = (9 << 8) + 200
+    split = np.array([0, x16, x16, x16, 65536], dtype=np.int64)
+    total = int(l1.sum())
+    cuts = {r: (x16, r * total // world) for r in range(1, world)}
+    counts = rsd.exchange_counts(l1, l2, split, world, cuts)
+    assert counts.sum() == total and np.array_equal(counts.sum(axis=1), l1[:, 9])
+    assert list(counts.sum(axis=0)) == [500, 500, 500, 500]
+    assert list(counts[0]) == [500, 500, 0, 0] and list(counts[1]) == [0, 0, 10, 0]      # sources in rank order

@@ -103,3 +103,6 @@ def test_multi_gpu_bench_script_rehearsal():
     for row in line["rows"]:
         assert all(row["parity"].values()), row
         assert sum(row["keys_per_rank_after_exchange"]) == 2 * (1 << 21)
+        ph = row["phase_ms_max_over_ranks"]                    # the per-phase clocks of the extra, synchronised sort
+        assert ph["partition_top_digit"] > 0 and ph["exchange"] > 0 and ph["local_sort"] > 0
+        assert row["bytes_sent_all_ranks"] > 0
