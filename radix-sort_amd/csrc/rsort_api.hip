@@ -700,7 +700,8 @@ int rs_ctx_create(rs_ctx** out, int device) {
     c->static_scratch = static_cast<char*>(p);
   }
   // Ranking shortcut: usable only if returning LDS adds of one wave instruction are served in lane order.
-  // Probed here on this device (about 2 million lane-operations over six collision patterns); any violation,
+  // Probed here on this device with the very functions the kernels rank with (rsk::rank_add / rank_add_peeled on
+  // 16-bit cells, 1024-thread workgroups two to a CU, 1.0e8 lane-operations, eight collision patterns); any violation,
   // or any failure of the probe itself, keeps the ballot-based ranking.
   {
     const char* env = std::getenv("RSORT_RANK");      // "ballot" forces the ballot form (tests, A/B timing)
@@ -708,7 +709,7 @@ int rs_ctx_create(rs_ctx** out, int device) {
     unsigned h_bad = 1;
     if (!(env && std::strcmp(env, "ballot") == 0) && hipMalloc(&d_bad, sizeof(unsigned)) == hipSuccess) {
       if (hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream) == hipSuccess) {
-        hipLaunchKernelGGL(rsk::lds_order_probe_kernel, dim3(64), dim3(256), 0, c->stream, d_bad, 120);
+        hipLaunchKernelGGL(rsk::lds_order_probe_kernel, dim3(512), dim3(1024), 0, c->stream, d_bad, 192);
         if (hipMemcpyAsync(&h_bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess)
           h_bad = 1;

@@ -460,22 +460,54 @@ struct SpinGuard {
   }
 };
 
-// Probe for the ranking shortcut: every lane does a returning LDS add on a word chosen by `mode`; a lane counts a
-// violation if the value it got back is not (word before the instruction) + (lower active lanes on the same word).
-__global__ __launch_bounds__(256) void lds_order_probe_kernel(unsigned* violations, int rounds) {
-  __shared__ unsigned hist[4][kRadix];
+// ---- ranking by returning LDS adds: the two forms every sweep kernel, the single-workgroup kernel AND the probe use ----
+// wwords: the wave's 256 digit counters as 16-bit cells, two to a 32-bit word (cell d = half (d & 1) of word d >> 1).
+// rank_add: one returning add per lane; lanes of one wave instruction that hit the same word (the same digit, or the two
+// digits that share it) must be served in lane order for the ranks to be stable -- what lds_order_probe_kernel checks.
+__device__ __forceinline__ unsigned rank_add(unsigned* wwords, unsigned d) {
+  return (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+}
+// rank_add_peeled: when at least 16 active lanes hold the first active lane's digit, that lane adds their number once
+// and the others take its answer plus their position among them; the remaining lanes add one each as above.
+// Call with the active lanes only (EXEC = the lanes that hold a key).
+__device__ __forceinline__ unsigned rank_add_peeled(unsigned* wwords, unsigned d) {
+  const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+  const bool mine = d == d0;
+  const unsigned long long same = __ballot(mine);
+  if (__popcll(same) >= 16) {
+    const unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
+    unsigned ret = 0;
+    if (!mine || below == 0)
+      ret = (atomicAdd(&wwords[d >> 1], (mine ? static_cast<unsigned>(__popcll(same)) : 1u) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+    const unsigned base0 = __builtin_amdgcn_readfirstlane(ret);   // the first active lane holds d0 and is its leader
+    return mine ? base0 + below : ret;
+  }
+  return rank_add(wwords, d);
+}
+
+// Probe for the ranking shortcut, on exactly the forms the kernels run: 1024-thread workgroups (two per CU), one 16-bit-cell
+// histogram per wave with two cells to a word, rank_add and rank_add_peeled as the kernels call them (the latter with
+// EXEC restricted to the active lanes).  Every lane checks the rank it got against the ballot form's answer: (cell before
+// the instruction) + (lower active lanes with the same digit).  Digit patterns: uniform, four values, one value (the
+// peeled leader adds the population), neighbouring digits 2k / 2k+1 (different cells of ONE word), runs of four lanes, a
+// 37-value mix, and a quarter of the lanes inactive.  512 workgroups x 192 rounds = 1.0e8 lane-operations, about 100 us.
+__global__ __launch_bounds__(1024) void lds_order_probe_kernel(unsigned* violations, int rounds) {
+  __shared__ unsigned short hist[16][kRadix];
   const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  for (unsigned i = lane; i < kRadix; i += kWave) hist[wave][i] = 0;
+  unsigned* wwords = reinterpret_cast<unsigned*>(hist[wave]);
+  for (unsigned i = lane; i < kRadix / 2; i += kWave) wwords[i] = 0;
   __syncthreads();
   unsigned bad = 0;
   for (int r = 0; r < rounds; ++r) {
     unsigned long long h = (static_cast<unsigned long long>(blockIdx.x) << 40) ^ (static_cast<unsigned long long>(r) << 16) ^ threadIdx.x;
     h += 0x9E3779B97F4A7C15ull; h = (h ^ (h >> 30)) * 0xBF58476D1CE4E5B9ull; h = (h ^ (h >> 27)) * 0x94D049BB133111EBull; h ^= h >> 31;
-    const int mode = r % 6;
-    unsigned d = mode == 0 ? (h & 255u) : mode == 1 ? (h & 3u) : mode == 2 ? 7u : mode == 3 ? (lane >> 2) + (h & 1u)
-               : static_cast<unsigned>((h >> 8) % 37u);
-    const bool active = mode != 5 || ((h >> 20) & 3u) != 0;
-    const unsigned before = hist[wave][d];
+    const int mode = r % 8;
+    const unsigned d = mode == 0 ? (h & 255u) : mode == 1 ? (h & 3u) : mode == 2 ? 7u : mode == 3 ? 2u * ((r >> 3) & 127u) + (h & 1u)
+                     : mode == 4 ? (lane >> 2) + (h & 1u) : mode == 5 ? static_cast<unsigned>((h >> 8) % 37u) : (h >> 12) & 255u;
+    const bool active = mode < 6 || ((h >> 20) & 3u) != 0;
+    // the ballot form's answer
+    const unsigned before = (__hip_atomic_load(&wwords[d >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> ((d & 1u) * 16)) & 0xFFFFu;
     unsigned dlo, dhi;
     differ_mask(d, dlo, dhi);
     const unsigned long long alive = __ballot(active);
@@ -483,9 +515,13 @@ __global__ __launch_bounds__(256) void lds_order_probe_kernel(unsigned* violatio
                                                      __builtin_amdgcn_mbcnt_lo(~dlo & static_cast<unsigned>(alive), 0u));
     __builtin_amdgcn_wave_barrier();
     unsigned got = 0;
-    if (active) got = atomicAdd(&hist[wave][d], 1u);
+    if (active) got = (mode == 2 || mode == 7 || (r & 8)) ? rank_add_peeled(wwords, d) : rank_add(wwords, d);
     __builtin_amdgcn_wave_barrier();
     if (active && got != before + below) ++bad;
+    if ((r & 63) == 63) {                      // keep the 16-bit cells far from overflow
+      for (unsigned i = lane; i < kRadix / 2; i += kWave) wwords[i] = 0;
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   if (bad) atomicAdd(violations, bad);
 }
@@ -714,22 +750,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
           unsigned d = digit_at(key[i], a.shift, a.bits);
           dig[i] = static_cast<unsigned char>(d);
           unsigned r = 0;
-          if (full || (seg + i * kWave) < tile_count) {
-            unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-            bool mine = d == d0;
-            unsigned long long same = __ballot(mine);
-            if (__popcll(same) >= 16) {
-              unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
-              unsigned ret = 0;
-              if (!mine || below == 0)
-                ret = (atomicAdd(&wwords[d >> 1], (mine ? static_cast<unsigned>(__popcll(same)) : 1u) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
-              unsigned base0 = __builtin_amdgcn_readfirstlane(ret);   // the first active lane holds d0 and is its leader
-              r = mine ? base0 + below : ret;
-            } else {
-              r = (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
-            }
-          }
+          if (full || (seg + i * kWave) < tile_count) r = rank_add_peeled(wwords, d);
           rank[i] = static_cast<unsigned short>(r);
         }
       } else {
@@ -738,8 +759,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
           unsigned d = digit_at(key[i], a.shift, a.bits);
           dig[i] = static_cast<unsigned char>(d);
           unsigned r = 0;
-          if (full || (seg + i * kWave) < tile_count)
-            r = (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+          if (full || (seg + i * kWave) < tile_count) r = rank_add(wwords, d);
           rank[i] = static_cast<unsigned short>(r);
         }
       }
@@ -760,7 +780,9 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
         phi &= static_cast<unsigned>(alive >> 32);
       }
       unsigned below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
-      unsigned before = s.whist[wave][d];
+      // (read through the same word pointer the adds use, as an atomic load: a plain 16-bit load of the cell would alias
+      // the previous round's add through an unrelated type and could legally be hoisted above it)
+      unsigned before = (__hip_atomic_load(&wwords[d >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> ((d & 1u) * 16)) & 0xFFFFu;
       if (ok && below == 0) atomicAdd(&wwords[d >> 1], static_cast<unsigned>(__popc(plo) + __popc(phi)) << ((d & 1u) * 16));
       rank[i] = static_cast<unsigned short>(before + below);
     }
@@ -1086,22 +1108,7 @@ __global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
     for (int i = 0; i < ITEMS; ++i) {
       const unsigned d = digit_at(key[i], shift, bits);
       unsigned r = 0;
-      if (seg + i * kWave < n) {
-        unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-        bool mine = d == d0;
-        unsigned long long same = __ballot(mine);
-        if (__popcll(same) >= 16) {
-          unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
-          unsigned ret = 0;
-          if (!mine || below == 0)
-            ret = (atomicAdd(&wwords[d >> 1], (mine ? static_cast<unsigned>(__popcll(same)) : 1u) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
-          unsigned base0 = __builtin_amdgcn_readfirstlane(ret);
-          r = mine ? base0 + below : ret;
-        } else {
-          r = (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
-        }
-      }
+      if (seg + i * kWave < n) r = rank_add_peeled(wwords, d);
       rank[i] = static_cast<unsigned short>(r);
     }
     __syncthreads();
