@@ -486,6 +486,28 @@ __device__ __forceinline__ unsigned rank_add_peeled(unsigned* wwords, unsigned d
   return rank_add(wwords, d);
 }
 
+// rank_add_runs: for rounds whose lanes hold few, CONTIGUOUS runs of equal digits (ordered inputs whose neighbours share a
+// digit: a float ramp repeats every value 16-128 times, so a round holds 2-4 runs of adjacent digits, two of them to a
+// word, and only one run can be peeled).  The first lane of every run adds the run's length; the others take what it
+// got plus their distance from it.  Two runs of one digit in a round (A B A) are two adds on one cell in one instruction,
+// served in lane order like any other pair.  Correct for any digits -- with 64 runs it is rank_add with more work.
+// Call with the active lanes only, which must be a prefix of the wave (they are: lane l holds key seg + i * 64 + l).
+__device__ __forceinline__ unsigned rank_add_runs(unsigned* wwords, unsigned d) {
+  const unsigned lane = lane_id();
+  const unsigned prev = __shfl_up(d, 1, kWave);                      // lane 0: its own digit
+  const unsigned long long act = __ballot(true);
+  const unsigned long long heads = __ballot(lane == 0 || prev != d);   // active lanes only, lane 0 always
+  const unsigned long long upto = heads & (~0ull >> (63u - lane));    // heads at or below this lane: never empty
+  const unsigned head_lane = 63u - static_cast<unsigned>(__clzll(static_cast<long long>(upto)));
+  const unsigned long long above = lane == 63u ? 0ull : heads >> (lane + 1u);
+  const unsigned run_end = above ? lane + static_cast<unsigned>(__ffsll(static_cast<long long>(above)))
+                                 : static_cast<unsigned>(__popcll(act));      // next head, or one past the last active lane
+  unsigned got = 0;
+  if (head_lane == lane)
+    got = (atomicAdd(&wwords[d >> 1], (run_end - lane) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+  return static_cast<unsigned>(__shfl(static_cast<int>(got), static_cast<int>(head_lane), kWave)) + (lane - head_lane);
+}
+
 // Probe for the ranking shortcut, on exactly the forms the kernels run: 1024-thread workgroups (two per CU), one 16-bit-cell
 // histogram per wave with two cells to a word, rank_add and rank_add_peeled as the kernels call them (the latter with
 // EXEC restricted to the active lanes).  Every lane checks the rank it got against the ballot form's answer: (cell before
@@ -515,7 +537,10 @@ __global__ __launch_bounds__(1024) void lds_order_probe_kernel(unsigned* violati
                                                      __builtin_amdgcn_mbcnt_lo(~dlo & static_cast<unsigned>(alive), 0u));
     __builtin_amdgcn_wave_barrier();
     unsigned got = 0;
-    if (active) got = (mode == 2 || mode == 7 || (r & 8)) ? rank_add_peeled(wwords, d) : rank_add(wwords, d);
+    if (active) {
+      if (mode < 6 && (r & 16)) got = rank_add_runs(wwords, d);              // (needs a prefix of lanes: not with the random inactive lanes)
+      else got = (mode == 2 || mode == 7 || (r & 8)) ? rank_add_peeled(wwords, d) : rank_add(wwords, d);
+    }
     __builtin_amdgcn_wave_barrier();
     if (active && got != before + below) ++bad;
     if ((r & 63) == 63) {                      // keep the 16-bit cells far from overflow
@@ -735,6 +760,22 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     // is made once per group of four rounds, on the group's first round: random digits then pay 9 instructions per
     // key instead of 15.  A group that is not peeled but should have been is still ranked correctly, only slower.
     static_assert(ITEMS % 4 == 0, "rounds are ranked in groups of four");
+    // A wave whose rounds are a few CONTIGUOUS runs of equal digits (an ordered input whose neighbours share a digit: a
+    // float ramp repeats every value 8-128 times) ranks all its rounds by run heads; peeling would take out one run only,
+    // and often none (no run reaches 16 lanes).  Looked at once per tile, on the wave's first round, so that random
+    // digits pay a third of an instruction per key for it: one DPP move (the digit of the lane below, inside rows of 16
+    // lanes), one compare, one count.  Row starts count as heads, so one run over the whole wave reads 4 -- that case
+    // stays with the peel, its cheapest form -- and random digits read about 64.
+    bool runs_group = false;
+    {
+      const unsigned d = digit_at(key[0], a.shift, a.bits);
+      if (full || seg < tile_count) {
+        const unsigned below = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(~d), static_cast<int>(d), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+        const unsigned heads = static_cast<unsigned>(__popcll(__ballot(below != d)));
+        runs_group = heads > 4 && heads <= 20;
+      }
+      runs_group = __builtin_amdgcn_readfirstlane(runs_group ? 1 : 0) != 0;
+    }
 #pragma unroll
     for (int g = 0; g < ITEMS; g += 4) {
       bool peel_group = false;
@@ -744,6 +785,16 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
           peel_group = __popcll(__ballot(d == static_cast<unsigned>(__builtin_amdgcn_readfirstlane(d)))) >= 16;
         peel_group = __builtin_amdgcn_readfirstlane(peel_group ? 1 : 0) != 0;   // lane 0 is valid whenever any lane is
       }
+      if (runs_group) {
+#pragma unroll
+        for (int i = g; i < g + 4; ++i) {
+          unsigned d = digit_at(key[i], a.shift, a.bits);
+          dig[i] = static_cast<unsigned char>(d);
+          unsigned r = 0;
+          if (full || (seg + i * kWave) < tile_count) r = rank_add_runs(wwords, d);
+          rank[i] = static_cast<unsigned short>(r);
+        }
+      } else
       if (peel_group) {
 #pragma unroll
         for (int i = g; i < g + 4; ++i) {
