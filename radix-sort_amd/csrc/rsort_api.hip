@@ -266,9 +266,12 @@ void launch_sweep_k(const rsk::SweepArgs& a, const SweepLaunch& l) {
 
 // Persistent grid for the histogram: its LDS table is key_bytes x 16 KB (rsk::kHistCols), so one
 // workgroup per CU for 8-byte keys, two otherwise; each workgroup strides over the keys.
+constexpr unsigned hist_wgs_per_cu(int key_bytes) {      // LDS table = key_bytes x 256 x kHistCols x 4 bytes
+  return static_cast<size_t>(key_bytes) * 256 * rsk::kHistCols * 4 <= 80 * 1024 ? 2u : 1u;
+}
 unsigned hist_grid(size_t n, int key_bytes) {
   const size_t per_block = static_cast<size_t>(kHistBlock) * 16 / key_bytes * 4;
-  const size_t resident = 256 * (key_bytes == 8 ? 1 : 2);
+  const size_t resident = 256 * hist_wgs_per_cu(key_bytes);
   return static_cast<unsigned>(std::max<size_t>(std::min<size_t>((n + per_block - 1) / per_block, resident), 1));
 }
 
@@ -469,7 +472,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
   h.chain_hist = chain ? chain_hist : nullptr;
   h.chain_keys = chain ? static_cast<uint64_t>(chain_tiles) * tile_keys(key_bytes, value_bytes, true) : 0;
-  launch_hist(h, key_bytes, chain ? 256u * (key_bytes == 8 ? 1 : 2) : hist_grid(n, key_bytes), s);
+  launch_hist(h, key_bytes, chain ? 256u * hist_wgs_per_cu(key_bytes) : hist_grid(n, key_bytes), s);
   hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase,
                      static_cast<const unsigned long long*>(chain ? chain_hist : nullptr));
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));

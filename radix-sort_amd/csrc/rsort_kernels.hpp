@@ -213,7 +213,10 @@ constexpr unsigned kChainHistStride = 8 * 256;   // words between two chains' ta
 // A single [pass][digit] table took ~11 cycles per wave instruction on random digits (bank
 // conflicts) and serialised 64 ways on sorted / few-valued inputs; this layout needs no special
 // case for either.  16 KB per pass: 64 KB for 4-byte keys (two workgroups per CU), 128 KB for 8-byte.
-constexpr int kHistCols = 16;
+#ifndef RS_HIST_COLS
+#define RS_HIST_COLS 16
+#endif
+constexpr int kHistCols = RS_HIST_COLS;
 
 // WHOLE = the sort covers the whole key in byte-aligned digits (begin_bit 0, end_bit 8*sizeof(K)):
 // every shift is a compile-time constant (one v_bfe_u32 with immediates per digit).

@@ -91,6 +91,11 @@ int main(int argc, char** argv) {
   if (kb == 4) check<uint32_t><<<2048, 256>>>((uint32_t*)work, n, bad, sums + 1); else check<uint64_t><<<2048, 256>>>((uint64_t*)work, n, bad, sums + 1);
   unsigned hb; unsigned long long hs[2];
   CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hs, sums, 16, hipMemcpyDeviceToHost));
+  // a sort answered by the order pre-check, or one whose passes were all skipped, leaves no per-pass times: indexing the
+  // empty vectors below was this harness' segmentation fault of round 1 (gpurun_out/tune16.log, rc 139)
+  if (tot.empty()) tot.push_back(0.f);
+  if (hist.empty()) hist.push_back(0.f);
+  if (pass.empty()) pass.push_back(0.f);
   std::sort(tot.begin(), tot.end()); std::sort(hist.begin(), hist.end()); std::sort(pass.begin(), pass.end());
   double t = tot[tot.size() / 2];
   double canon = (double)n * (kb + 2.0 * kb * (kb + vb));
