@@ -65,8 +65,11 @@ constexpr int kMaxPasses = 8;
 #ifndef RS_SWEEP_ITEMS_WIDE
 #define RS_SWEEP_ITEMS_WIDE 16
 #endif
-constexpr int sweep_items(int key_bytes, int value_bytes) {
-  return (key_bytes <= 4 && value_bytes <= 4) ? RS_SWEEP_ITEMS : RS_SWEEP_ITEMS_WIDE;
+#ifndef RS_CHAIN_ITEMS     // keys per thread of the narrow chain-mode kernels
+#define RS_CHAIN_ITEMS 16
+#endif
+constexpr int sweep_items(int key_bytes, int value_bytes, bool chain = false) {
+  return (key_bytes <= 4 && value_bytes <= 4) ? (chain ? RS_CHAIN_ITEMS : RS_SWEEP_ITEMS) : RS_SWEEP_ITEMS_WIDE;
 }
 constexpr bool narrow_geometry(int key_bytes, int value_bytes) { return key_bytes <= 4 && value_bytes <= 4; }
 constexpr int sweep_block(int key_bytes, int value_bytes, bool chain = false) {
@@ -180,7 +183,7 @@ int ensure(rs_ctx* c, DevBuf& b, size_t bytes) {
 }
 
 size_t tile_keys(int key_bytes, int value_bytes, bool chain = false) {
-  return static_cast<size_t>(sweep_block(key_bytes, value_bytes, chain)) * sweep_items(key_bytes, value_bytes);
+  return static_cast<size_t>(sweep_block(key_bytes, value_bytes, chain)) * sweep_items(key_bytes, value_bytes, chain);
 }
 size_t tiles_for(size_t n, int key_bytes, int value_bytes, bool chain = false) {
   const size_t t = tile_keys(key_bytes, value_bytes, chain);
@@ -215,6 +218,7 @@ void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, bool 
   if constexpr (kVal == 0 ? sizeof(K) >= 4 : (sizeof(K) == 8 && kVal == 4)) {   // the shapes sort_device selects chain mode for
     if (chain) {   // persistent workgroups, one chain of tiles per XCD (only with the returning-add ranking)
       constexpr int kBlockC = sweep_block(static_cast<int>(sizeof(K)), kVal, true);
+      constexpr int kItemsC = sweep_items(static_cast<int>(sizeof(K)), kVal, true);
       constexpr int kMinBlocksC = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_CHAIN_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
       auto launch = [&](auto kernel) {
         static const int per_cu = [&] {      // resident workgroups per CU (registers, LDS, wave slots)
@@ -225,8 +229,8 @@ void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, bool 
         hipLaunchKernelGGL(kernel, dim3(chain_grid * per_cu), dim3(kBlockC), 0, s, a);
       };
       // the last launched pass has no next digit to count for
-      if (a.next_cnt) launch(rsk::onesweep_kernel<K, V, D, kBlockC, kItems, RS_LOOKBACK_CHAIN, kMinBlocksC, true, true, true>);
-      else launch(rsk::onesweep_kernel<K, V, D, kBlockC, kItems, RS_LOOKBACK_CHAIN, kMinBlocksC, true, true, false>);
+      if (a.next_cnt) launch(rsk::onesweep_kernel<K, V, D, kBlockC, kItemsC, RS_LOOKBACK_CHAIN, kMinBlocksC, true, true, true>);
+      else launch(rsk::onesweep_kernel<K, V, D, kBlockC, kItemsC, RS_LOOKBACK_CHAIN, kMinBlocksC, true, true, false>);
       return;
     }
   }
@@ -703,16 +707,18 @@ int rs_ctx_create(rs_ctx** out, int device) {
     c->static_scratch = static_cast<char*>(p);
   }
   // Ranking shortcut: usable only if returning LDS adds of one wave instruction are served in lane order.
-  // Probed here on this device with the very functions the kernels rank with (rsk::rank_add / rank_add_peeled on
-  // 16-bit cells, 1024-thread workgroups two to a CU, 1.0e8 lane-operations, eight collision patterns); any violation,
-  // or any failure of the probe itself, keeps the ballot-based ranking.
+  // Probed here on this device with the very functions the kernels rank with (rsk::rank_add / rank_add_peeled /
+  // rank_add_runs, on both cell layouts: 16-bit cells in 1024-thread workgroups two to a CU, 32-bit cells in 512-thread
+  // workgroups; 1.5e8 lane-operations, eight collision patterns); any violation, or any failure of the probe itself,
+  // keeps the ballot-based ranking.
   {
     const char* env = std::getenv("RSORT_RANK");      // "ballot" forces the ballot form (tests, A/B timing)
     unsigned* d_bad = nullptr;
     unsigned h_bad = 1;
     if (!(env && std::strcmp(env, "ballot") == 0) && hipMalloc(&d_bad, sizeof(unsigned)) == hipSuccess) {
       if (hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream) == hipSuccess) {
-        hipLaunchKernelGGL(rsk::lds_order_probe_kernel, dim3(512), dim3(1024), 0, c->stream, d_bad, 192);
+        hipLaunchKernelGGL((rsk::lds_order_probe_kernel<false, 1024>), dim3(512), dim3(1024), 0, c->stream, d_bad, 192);
+        hipLaunchKernelGGL((rsk::lds_order_probe_kernel<true, 512>), dim3(512), dim3(512), 0, c->stream, d_bad, 192);
         if (hipMemcpyAsync(&h_bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess)
           h_bad = 1;

@@ -463,17 +463,31 @@ struct SpinGuard {
   }
 };
 
-// ---- ranking by returning LDS adds: the two forms every sweep kernel, the single-workgroup kernel AND the probe use ----
-// wwords: the wave's 256 digit counters as 16-bit cells, two to a 32-bit word (cell d = half (d & 1) of word d >> 1).
-// rank_add: one returning add per lane; lanes of one wave instruction that hit the same word (the same digit, or the two
-// digits that share it) must be served in lane order for the ranks to be stable -- what lds_order_probe_kernel checks.
-__device__ __forceinline__ unsigned rank_add(unsigned* wwords, unsigned d) {
-  return (atomicAdd(&wwords[d >> 1], 1u << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+// ---- ranking by returning LDS adds: the forms every sweep kernel, the single-workgroup kernel AND the probe use ----
+// cells: the wave's 256 digit counters.  Two layouts:
+//   WIDE = false  16-bit cells, two to a 32-bit word (cell d = half (d & 1) of word d >> 1): 512 bytes per wave, what lets
+//                 two 16384-key workgroups of 16 waves share a CU;
+//   WIDE = true   one 32-bit word per digit (1 KB per wave; the 512-thread chain kernels, which have the LDS for it): the
+//                 address is one shift-add, the add is the constant 1 and the answer needs no extraction -- 2 instead of 7
+//                 vector instructions per key around the LDS operation.
+// cell_add: one returning add per lane; lanes of one wave instruction that hit the same word (the same digit, or -- 16-bit
+// cells -- the two digits that share it) must be served in lane order for the ranks to be stable: what
+// lds_order_probe_kernel checks, for both layouts.
+template <bool WIDE> __device__ __forceinline__ unsigned cell_add(unsigned* cells, unsigned d, unsigned amount) {
+  if constexpr (WIDE) return atomicAdd(&cells[d], amount);
+  else return (atomicAdd(&cells[d >> 1], amount << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+}
+template <bool WIDE> __device__ __forceinline__ unsigned cell_load(const unsigned* cells, unsigned d) {
+  if constexpr (WIDE) return __hip_atomic_load(&cells[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else return (__hip_atomic_load(&cells[d >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> ((d & 1u) * 16)) & 0xFFFFu;
+}
+template <bool WIDE = false> __device__ __forceinline__ unsigned rank_add(unsigned* cells, unsigned d) {
+  return cell_add<WIDE>(cells, d, 1u);
 }
 // rank_add_peeled: when at least 16 active lanes hold the first active lane's digit, that lane adds their number once
 // and the others take its answer plus their position among them; the remaining lanes add one each as above.
 // Call with the active lanes only (EXEC = the lanes that hold a key).
-__device__ __forceinline__ unsigned rank_add_peeled(unsigned* wwords, unsigned d) {
+template <bool WIDE = false> __device__ __forceinline__ unsigned rank_add_peeled(unsigned* cells, unsigned d) {
   const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
   const bool mine = d == d0;
   const unsigned long long same = __ballot(mine);
@@ -481,12 +495,11 @@ __device__ __forceinline__ unsigned rank_add_peeled(unsigned* wwords, unsigned d
     const unsigned below = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(same >> 32),
                                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(same), 0u));
     unsigned ret = 0;
-    if (!mine || below == 0)
-      ret = (atomicAdd(&wwords[d >> 1], (mine ? static_cast<unsigned>(__popcll(same)) : 1u) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+    if (!mine || below == 0) ret = cell_add<WIDE>(cells, d, mine ? static_cast<unsigned>(__popcll(same)) : 1u);
     const unsigned base0 = __builtin_amdgcn_readfirstlane(ret);   // the first active lane holds d0 and is its leader
     return mine ? base0 + below : ret;
   }
-  return rank_add(wwords, d);
+  return rank_add<WIDE>(cells, d);
 }
 
 // rank_add_runs: for rounds whose lanes hold few, CONTIGUOUS runs of equal digits (ordered inputs whose neighbours share a
@@ -495,7 +508,7 @@ __device__ __forceinline__ unsigned rank_add_peeled(unsigned* wwords, unsigned d
 // got plus their distance from it.  Two runs of one digit in a round (A B A) are two adds on one cell in one instruction,
 // served in lane order like any other pair.  Correct for any digits -- with 64 runs it is rank_add with more work.
 // Call with the active lanes only, which must be a prefix of the wave (they are: lane l holds key seg + i * 64 + l).
-__device__ __forceinline__ unsigned rank_add_runs(unsigned* wwords, unsigned d) {
+template <bool WIDE = false> __device__ __forceinline__ unsigned rank_add_runs(unsigned* cells, unsigned d) {
   const unsigned lane = lane_id();
   const unsigned prev = __shfl_up(d, 1, kWave);                      // lane 0: its own digit
   const unsigned long long act = __ballot(true);
@@ -506,22 +519,25 @@ __device__ __forceinline__ unsigned rank_add_runs(unsigned* wwords, unsigned d) 
   const unsigned run_end = above ? lane + static_cast<unsigned>(__ffsll(static_cast<long long>(above)))
                                  : static_cast<unsigned>(__popcll(act));      // next head, or one past the last active lane
   unsigned got = 0;
-  if (head_lane == lane)
-    got = (atomicAdd(&wwords[d >> 1], (run_end - lane) << ((d & 1u) * 16)) >> ((d & 1u) * 16)) & 0xFFFFu;
+  if (head_lane == lane) got = cell_add<WIDE>(cells, d, run_end - lane);
   return static_cast<unsigned>(__shfl(static_cast<int>(got), static_cast<int>(head_lane), kWave)) + (lane - head_lane);
 }
 
-// Probe for the ranking shortcut, on exactly the forms the kernels run: 1024-thread workgroups (two per CU), one 16-bit-cell
-// histogram per wave with two cells to a word, rank_add and rank_add_peeled as the kernels call them (the latter with
-// EXEC restricted to the active lanes).  Every lane checks the rank it got against the ballot form's answer: (cell before
-// the instruction) + (lower active lanes with the same digit).  Digit patterns: uniform, four values, one value (the
-// peeled leader adds the population), neighbouring digits 2k / 2k+1 (different cells of ONE word), runs of four lanes, a
-// 37-value mix, and a quarter of the lanes inactive.  512 workgroups x 192 rounds = 1.0e8 lane-operations, about 100 us.
-__global__ __launch_bounds__(1024) void lds_order_probe_kernel(unsigned* violations, int rounds) {
-  __shared__ unsigned short hist[16][kRadix];
+// Probe for the ranking shortcut, on exactly the forms the kernels run: both cell layouts (WIDE = false in 1024-thread
+// workgroups, two per CU, as the one-chain kernels; WIDE = true in 512-thread workgroups as the chain kernels), one
+// histogram per wave, rank_add, rank_add_peeled and rank_add_runs as the kernels call them (the first two also with EXEC
+// restricted to the active lanes).  Every lane checks the rank it got against the ballot form's answer: (cell before the
+// instruction) + (lower active lanes with the same digit).  Digit patterns: uniform, four values, one value (the peeled
+// leader adds the population), neighbouring digits 2k / 2k+1 (different cells of ONE word when cells are 16 bits), runs
+// of four lanes, a 37-value mix, and a quarter of the lanes inactive.  512 workgroups x 1024 threads x 192 rounds = 1.0e8
+// lane-operations for the packed layout and half as many for the wide one, about 100 us each.
+template <bool WIDE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void lds_order_probe_kernel(unsigned* violations, int rounds) {
+  constexpr int kCellWords = WIDE ? kRadix : kRadix / 2;
+  __shared__ unsigned hist[BLOCK / kWave][kCellWords];
   const unsigned lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  unsigned* wwords = reinterpret_cast<unsigned*>(hist[wave]);
-  for (unsigned i = lane; i < kRadix / 2; i += kWave) wwords[i] = 0;
+  unsigned* cells = hist[wave];
+  for (unsigned i = lane; i < kCellWords; i += kWave) cells[i] = 0;
   __syncthreads();
   unsigned bad = 0;
   for (int r = 0; r < rounds; ++r) {
@@ -532,7 +548,7 @@ __global__ __launch_bounds__(1024) void lds_order_probe_kernel(unsigned* violati
                      : mode == 4 ? (lane >> 2) + (h & 1u) : mode == 5 ? static_cast<unsigned>((h >> 8) % 37u) : (h >> 12) & 255u;
     const bool active = mode < 6 || ((h >> 20) & 3u) != 0;
     // the ballot form's answer
-    const unsigned before = (__hip_atomic_load(&wwords[d >> 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> ((d & 1u) * 16)) & 0xFFFFu;
+    const unsigned before = cell_load<WIDE>(cells, d);
     unsigned dlo, dhi;
     differ_mask(d, dlo, dhi);
     const unsigned long long alive = __ballot(active);
@@ -541,13 +557,13 @@ __global__ __launch_bounds__(1024) void lds_order_probe_kernel(unsigned* violati
     __builtin_amdgcn_wave_barrier();
     unsigned got = 0;
     if (active) {
-      if (mode < 6 && (r & 16)) got = rank_add_runs(wwords, d);              // (needs a prefix of lanes: not with the random inactive lanes)
-      else got = (mode == 2 || mode == 7 || (r & 8)) ? rank_add_peeled(wwords, d) : rank_add(wwords, d);
+      if (mode < 6 && (r & 16)) got = rank_add_runs<WIDE>(cells, d);          // (needs a prefix of lanes: not with the random inactive lanes)
+      else got = (mode == 2 || mode == 7 || (r & 8)) ? rank_add_peeled<WIDE>(cells, d) : rank_add<WIDE>(cells, d);
     }
     __builtin_amdgcn_wave_barrier();
     if (active && got != before + below) ++bad;
-    if ((r & 63) == 63) {                      // keep the 16-bit cells far from overflow
-      for (unsigned i = lane; i < kRadix / 2; i += kWave) wwords[i] = 0;
+    if ((r & 63) == 63) {                      // keep 16-bit cells far from overflow
+      for (unsigned i = lane; i < kCellWords; i += kWave) cells[i] = 0;
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -578,16 +594,18 @@ constexpr bool kCheckedStores = true;
 constexpr bool kCheckedStores = false;
 #endif
 
-template <typename K, typename V, typename D, int BLOCK, int ITEMS>
+template <typename K, typename V, typename D, int BLOCK, int ITEMS, bool WIDE_CELLS>
 struct SweepSmem {
+  using Cell = typename Pick<WIDE_CELLS, unsigned, unsigned short>::type;
   static constexpr int WAVES = BLOCK / kWave;
   static constexpr int TILE = BLOCK * ITEMS;
   static constexpr bool HAS_VAL = !__is_same(V, NoVal);
   static constexpr size_t kElem = HAS_VAL ? (sizeof(V) > sizeof(K) ? sizeof(V) : sizeof(K)) : sizeof(K);
   alignas(16) unsigned char stage[TILE * kElem];
   // per wave: running digit counts, later tile_start + wave prefix.  16-bit cells (a wave holds at most 64 x ITEMS
-  // keys, a tile fewer than 65536), updated two to a 32-bit LDS word: cell d lives in half (d & 1) of word d >> 1.
-  unsigned short whist[WAVES][kRadix];
+  // keys, a tile fewer than 65536), updated two to a 32-bit LDS word: cell d lives in half (d & 1) of word d >> 1;
+  // or one word per digit (WIDE_CELLS, see cell_add).
+  Cell whist[WAVES][kRadix];
   static_assert(TILE < 65536, "16-bit tile-local positions");
   unsigned tile_start[kRadix];      // exclusive scan of the tile's digit counts
   D gofs[kRadix];                   // global offset of the digit's run minus tile_start
@@ -623,7 +641,13 @@ struct NoChainSmem {};
 
 template <typename K, typename V, typename D, int BLOCK, int ITEMS, int LOOKBACK = 8, int MIN_BLOCKS = 1, bool RANK_BY_LDS_ATOMIC = true, bool CHAIN = false, bool COUNT = false>
 __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesweep_kernel(SweepArgs a) {
-  using Smem = SweepSmem<K, V, D, BLOCK, ITEMS>;
+#ifdef RS_NO_WIDE_CELLS
+  constexpr bool WIDE_CELLS = false;
+#else
+  constexpr bool WIDE_CELLS = CHAIN;     // the 512-thread chain kernels have the LDS for one word per digit and wave
+#endif
+  using Smem = SweepSmem<K, V, D, BLOCK, ITEMS, WIDE_CELLS>;
+  using Cell = typename Smem::Cell;
   constexpr int WAVES = Smem::WAVES;
   constexpr int TILE = Smem::TILE;
   constexpr bool HAS_VAL = Smem::HAS_VAL;
@@ -685,7 +709,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     s.out_of_range = 0;
   }
 #pragma unroll
-  for (int i = 0; i < kRadix / 2 / kWave; ++i) reinterpret_cast<unsigned*>(s.whist[wave])[i * kWave + lane] = 0;
+  for (int i = 0; i < static_cast<int>(sizeof(Cell)) * kRadix / 4 / kWave; ++i) reinterpret_cast<unsigned*>(s.whist[wave])[i * kWave + lane] = 0;
   __syncthreads();
 
   if (s.tile_id == kNoTile) break;                // workgroup-uniform; without CHAIN it cannot happen (one workgroup per tile)
@@ -695,10 +719,34 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   if (RS_STAMP_ON && tid == 0 && (tile & 63) == 0 && (tile >> 6) < 4096) rs_stamp_buf[tile >> 6] = stamp_begin;
 #endif
   RS_STAMP(1);
+  // A tile's way to its aggregate goes first.  The tiles behind it in the chain cannot finish their look-back before this
+  // tile has published its digit counts, so a wave that is loading or ranking is given priority at the CU's instruction
+  // arbiter over waves that are staging or writing out (s_setprio; back to 0 once the aggregate is out).  What this buys is
+  // less spread in the ticket-to-aggregate time, which is what successors wait for: uint64 pass 3.73 -> 3.53 ms, uint32
+  // 2.05 -> 2.01 ms at N = 2^30.  RS_PRIO_PRE_AGG=0 builds without it.
+#ifndef RS_PRIO_PRE_AGG
+#define RS_PRIO_PRE_AGG 2
+#endif
+#if RS_PRIO_PRE_AGG
+  __builtin_amdgcn_s_setprio(RS_PRIO_PRE_AGG);
+#endif
   const uint64_t tile_base = tile * TILE;
-  const unsigned tile_count = (a.n - tile_base) < static_cast<uint64_t>(TILE)
-                                  ? static_cast<unsigned>(a.n - tile_base) : static_cast<unsigned>(TILE);
-  const bool full = tile_count == TILE;
+  // Keys in this tile: TILE except in the last tile of the pass.  In 32-bit arithmetic on the tile number, on purpose: the
+  // 64-bit form `n - tile_base < TILE ? n - tile_base : TILE` followed by the uniform branch on `tile_count == TILE` below
+  // was miscompiled by hipcc 7.2.0 (the compare moved to the vector unit, v_cmp_lt_u64 -> VCC, while the s_cselect_b32
+  // that picks the count still read SCC, left over from an unrelated s_or_b64: the ragged tile of untransformed keys then
+  // ran with tile_count = TILE).
+  const unsigned last_count = static_cast<unsigned>(a.n - static_cast<uint64_t>(tiles_total - 1) * TILE);   // 1 .. TILE
+  const unsigned tile_count = s.tile_id == tiles_total - 1 ? last_count : static_cast<unsigned>(TILE);
+
+  // The rest of the tile exists twice: once for full tiles (all but the last tile of a pass), where no key needs a
+  // bounds test and every phase is straight-line code -- the sixteen returning adds of the ranking, the sixteen
+  // staging-area reads of the write-out are issued back to back and waited for once -- and once for the ragged last
+  // tile.  With the test `full || index < tile_count` evaluated at run time each key sat in its own EXEC-masked block
+  // and the compiler had to wait for every LDS answer before the next request (one s_waitcnt lgkmcnt(0) per key).
+  // Returns false when the workgroup must stop (a run of this tile would leave the array).
+  auto sweep_tile = [&](auto full_tag) -> bool {
+  constexpr bool full = decltype(full_tag)::value;
 
   const K* kin = static_cast<const K*>(a.keys_in) + tile_base;
   const K fmi = static_cast<K>(a.fmask_in), smi = static_cast<K>(a.smask_in);
@@ -707,7 +755,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   // ---- load: wave-striped, so (item, lane) order == key order inside the wave's segment ----------
   K key[ITEMS];
   const unsigned seg = wave * (kWave * ITEMS) + lane;
-  if (full && CHAIN) {
+  if constexpr (full && CHAIN) {
     // Chain mode (16-byte aligned buffers): the wave's segment comes in through LDS-DMA, 1 KB per instruction, into the
     // staging area (idle at this point), and is read back striped.  A 4-byte-per-lane load costs the CU's address unit as
     // much as a 16-byte one, and with single keys in both directions that unit, not HBM, bounds the pass (TA/TD 70-90 %
@@ -752,6 +800,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   unsigned short rank[ITEMS];
   unsigned char dig[ITEMS];
   unsigned* wwords = reinterpret_cast<unsigned*>(s.whist[wave]);   // the wave's cells as 32-bit words
+  static_assert(RANK_BY_LDS_ATOMIC || !CHAIN, "the ballot form knows the 16-bit cells only");
   if constexpr (RANK_BY_LDS_ATOMIC) {
     // rank = the value a returning LDS add hands back.  When several lanes of ONE wave instruction hit the same
     // word, gfx950 serves them in lane order (lds_order_probe_kernel below checks exactly this when a context
@@ -770,51 +819,59 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     // lanes), one compare, one count.  Row starts count as heads, so one run over the whole wave reads 4 -- that case
     // stays with the peel, its cheapest form -- and random digits read about 64.
     bool runs_group = false;
-    {
+    bool special = false;      // some group of four rounds wants the peeled or the run-head form (wave-uniform)
+    bool peel_group[ITEMS / 4];
+    if constexpr (full) {      // (the ragged last tile ranks by plain adds: correct for any digits, and it is one tile)
       const unsigned d = digit_at(key[0], a.shift, a.bits);
-      if (full || seg < tile_count) {
-        const unsigned below = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(~d), static_cast<int>(d), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
-        const unsigned heads = static_cast<unsigned>(__popcll(__ballot(below != d)));
-        runs_group = heads > 4 && heads <= 20;
+      const unsigned below = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(~d), static_cast<int>(d), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
+      const unsigned heads = static_cast<unsigned>(__popcll(__ballot(below != d)));
+      runs_group = heads > 4 && heads <= 20;
+      special = runs_group;
+#pragma unroll
+      for (int g = 0; g < ITEMS; g += 4) {
+        const unsigned dg = digit_at(key[g], a.shift, a.bits);
+        peel_group[g / 4] = __popcll(__ballot(dg == static_cast<unsigned>(__builtin_amdgcn_readfirstlane(dg)))) >= 16;
+        special |= peel_group[g / 4];
       }
-      runs_group = __builtin_amdgcn_readfirstlane(runs_group ? 1 : 0) != 0;
     }
+#ifdef RS_NO_RANK16
+    if constexpr (full) special = true;
+#endif
+    if (!special) {
+      // the common case (and the ragged tile): one returning add per key, all ITEMS of them in flight before the first
+      // answer is looked at
 #pragma unroll
-    for (int g = 0; g < ITEMS; g += 4) {
-      bool peel_group = false;
-      {
-        const unsigned d = digit_at(key[g], a.shift, a.bits);
-        if (full || (seg + g * kWave) < tile_count)
-          peel_group = __popcll(__ballot(d == static_cast<unsigned>(__builtin_amdgcn_readfirstlane(d)))) >= 16;
-        peel_group = __builtin_amdgcn_readfirstlane(peel_group ? 1 : 0) != 0;   // lane 0 is valid whenever any lane is
+      for (int i = 0; i < ITEMS; ++i) {
+        unsigned d = digit_at(key[i], a.shift, a.bits);
+        dig[i] = static_cast<unsigned char>(d);
+        unsigned r = 0;
+        if (full || (seg + i * kWave) < tile_count) r = rank_add<WIDE_CELLS>(wwords, d);
+        rank[i] = static_cast<unsigned short>(r);
       }
-      if (runs_group) {
+    } else {
 #pragma unroll
-        for (int i = g; i < g + 4; ++i) {
-          unsigned d = digit_at(key[i], a.shift, a.bits);
-          dig[i] = static_cast<unsigned char>(d);
-          unsigned r = 0;
-          if (full || (seg + i * kWave) < tile_count) r = rank_add_runs(wwords, d);
-          rank[i] = static_cast<unsigned short>(r);
-        }
-      } else
-      if (peel_group) {
+      for (int g = 0; g < ITEMS; g += 4) {
+        if (runs_group) {
 #pragma unroll
-        for (int i = g; i < g + 4; ++i) {
-          unsigned d = digit_at(key[i], a.shift, a.bits);
-          dig[i] = static_cast<unsigned char>(d);
-          unsigned r = 0;
-          if (full || (seg + i * kWave) < tile_count) r = rank_add_peeled(wwords, d);
-          rank[i] = static_cast<unsigned short>(r);
-        }
-      } else {
+          for (int i = g; i < g + 4; ++i) {
+            unsigned d = digit_at(key[i], a.shift, a.bits);
+            dig[i] = static_cast<unsigned char>(d);
+            rank[i] = static_cast<unsigned short>(rank_add_runs<WIDE_CELLS>(wwords, d));
+          }
+        } else if (peel_group[g / 4]) {
 #pragma unroll
-        for (int i = g; i < g + 4; ++i) {
-          unsigned d = digit_at(key[i], a.shift, a.bits);
-          dig[i] = static_cast<unsigned char>(d);
-          unsigned r = 0;
-          if (full || (seg + i * kWave) < tile_count) r = rank_add(wwords, d);
-          rank[i] = static_cast<unsigned short>(r);
+          for (int i = g; i < g + 4; ++i) {
+            unsigned d = digit_at(key[i], a.shift, a.bits);
+            dig[i] = static_cast<unsigned char>(d);
+            rank[i] = static_cast<unsigned short>(rank_add_peeled<WIDE_CELLS>(wwords, d));
+          }
+        } else {
+#pragma unroll
+          for (int i = g; i < g + 4; ++i) {
+            unsigned d = digit_at(key[i], a.shift, a.bits);
+            dig[i] = static_cast<unsigned char>(d);
+            rank[i] = static_cast<unsigned short>(rank_add<WIDE_CELLS>(wwords, d));
+          }
         }
       }
     }
@@ -843,6 +900,9 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   }
   __syncthreads();
   RS_STAMP(3);
+#if RS_PRIO_PRE_AGG
+  if (tid >= kRadix) __builtin_amdgcn_s_setprio(0);
+#endif
 
   // ---- per digit: tile count, publish the aggregate, scan over digits -----------------------------
   D* desc = static_cast<D*>(a.desc);
@@ -863,6 +923,9 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     }
     inc = v;
     if (lane == kWave - 1) s.wave_total[wave] = v;
+#if RS_PRIO_PRE_AGG
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
   __syncthreads();
   if (tid < kRadix) {
@@ -874,7 +937,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) {
       unsigned c = s.whist[w][tid];
-      s.whist[w][tid] = static_cast<unsigned short>(sum);
+      s.whist[w][tid] = static_cast<Cell>(sum);
       sum += c;
     }
   }
@@ -882,13 +945,25 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   RS_STAMP(4);
 
   // ---- stage keys in LDS in digit order -------------------------------------------------------------
+  // (two loops: all the reads of the wave's prefixes first, in flight together; in one loop every staging store, which the
+  // compiler must assume to alias the next read, waited for the read before it)
   K* stage_k = reinterpret_cast<K*>(s.stage);
 #pragma unroll
-  for (int i = 0; i < ITEMS; ++i) {
-    unsigned pos = s.whist[wave][dig[i]] + rank[i];
-    rank[i] = static_cast<unsigned short>(pos);
-    if (full || (seg + i * kWave) < tile_count) stage_k[stage_swizzle(pos)] = key[i];
-  }
+  for (int i = 0; i < ITEMS; ++i) rank[i] = static_cast<unsigned short>(s.whist[wave][dig[i]] + rank[i]);
+  auto stage_keys = [&](auto from_tag, auto to_tag) {
+#pragma unroll
+    for (int i = decltype(from_tag)::value; i < decltype(to_tag)::value; ++i)
+      if (full || (seg + i * kWave) < tile_count) stage_k[stage_swizzle(rank[i])] = key[i];
+  };
+#ifndef RS_LOOKBACK_FIRST
+#define RS_LOOKBACK_FIRST 0
+#endif
+  // The digit waves stage only their first ITEMS - kLate keys now and the others after the look-back, so that the
+  // inclusive prefix -- what the tiles behind this one wait for -- is published that much earlier.
+  constexpr int kLate = CHAIN ? RS_LOOKBACK_FIRST : 0;
+  static_assert(kLate >= 0 && kLate <= ITEMS, "keys staged after the look-back");
+  if (kLate == 0 || tid >= kRadix) stage_keys(std::integral_constant<int, 0>{}, std::integral_constant<int, ITEMS>{});
+  else stage_keys(std::integral_constant<int, 0>{}, std::integral_constant<int, ITEMS - kLate>{});
   RS_STAMP(5);
 
   // ---- decoupled look-back: one thread per digit, LOOKBACK predecessors per round trip --------------
@@ -947,84 +1022,121 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     // whatever produces them) make the two disagree.  A tile with a run that would end past the array reports that
     // and writes nothing: one compare per digit here instead of one per key in the write-out.
     if (my_count != 0 && run_begin + my_count > a.n) s.out_of_range = 1;
+    if constexpr (kLate > 0) stage_keys(std::integral_constant<int, ITEMS - kLate>{}, std::integral_constant<int, ITEMS>{});
   }
   __syncthreads();
   RS_STAMP(6);
   if (s.out_of_range) {                            // workgroup-uniform
     if (tid == 0) __hip_atomic_fetch_or(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    break;
+    return false;
   }
 
   // ---- write out: consecutive threads write consecutive addresses inside each digit run -------------
+  // In phases over all ITEMS rounds, each a straight line: read the staged keys, read their runs' offsets, count for the
+  // next pass, transform, store.  The LDS reads of a phase are independent and all in flight together; written as one loop
+  // over rounds the compiler kept one or two in flight (the counting adds are atomics, nothing moves across them).
   K* kout = static_cast<K*>(a.keys_out);
   const K fmo = static_cast<K>(a.fmask_out), smo = static_cast<K>(a.smask_out);
   const bool xf_out = (a.fmask_out | a.smask_out) != 0;
   D dst[HAS_VAL ? ITEMS : 1];
-  // One round of the write-out: staged key j = i * BLOCK + tid goes to its run.  Counting kernels also add the key to its
-  // (chain of the output position, next digit) cell.  PEEL selects how: 0 = one LDS add per key, straight-line code (a
-  // branch inside the rounds, even a wave-uniform one, keeps the compiler from overlapping their LDS reads and stores);
-  // 2 = the lanes that share the first lane's cell add once, through that lane, and so do the lanes that share the
-  // first remaining lane's cell.  The staged keys are in digit order, so on few-valued inputs the 64 lanes of a round
-  // hold one or two runs of EQUAL keys and would otherwise queue their adds on one or two words (256-value
-  // duplicates: 4.8 ms per uint32 pass instead of 2.1); on random keys the extra instructions cost 8 % of a pass,
-  // so every wave looks at its first round and picks the form for the other fifteen.
+  // staged element j = i * BLOCK + tid sits at stage_swizzle(j) = j ^ ((j >> 6) & 31).  BLOCK / 64 is a power of two of at
+  // most 32, so (j >> 6) & 31 = ((i * BLOCK / 64) & 31) | (tid >> 6) with no carry between the two parts, and the swizzled
+  // index is a per-round constant XOR a per-thread constant: one instruction per key instead of three.
+  static_assert((BLOCK / kWave) <= 32 && ((BLOCK / kWave) & (BLOCK / kWave - 1)) == 0, "swizzle split");
+  const unsigned sw_t = tid ^ (tid >> 6);
+  K wk[ITEMS];
+  D wo[ITEMS];
+  // Counting kernels add every key to its (chain of the output position, next digit) cell.  PEEL selects how: 0 = one LDS
+  // add per key, straight-line code; 2 = the lanes that share the first lane's cell add once, through that lane, and so do
+  // the lanes that share the first remaining lane's cell.  The staged keys are in digit order, so on few-valued inputs the
+  // 64 lanes of a round hold one or two runs of EQUAL keys and would otherwise queue their adds on one or two words
+  // (256-value duplicates: 4.8 ms per uint32 pass instead of 2.1); on random keys the extra instructions cost 8 % of a
+  // pass, so every wave looks at its first round and picks the form for the other fifteen.
   unsigned first_group = 0;          // lanes that shared the first lane's cell in round 0
-  auto write_round = [&](auto peel_tag, int i) {
+  auto count_round = [&](auto peel_tag, int i) {
     constexpr int PEEL = decltype(peel_tag)::value;
-    unsigned j = i * BLOCK + tid;
-    if (full || j < tile_count) {
-      K k = stage_k[stage_swizzle(j)];
-      D o = s.gofs[digit_at(k, a.shift, a.bits)] + j;
-      if constexpr (CHAIN && COUNT) {
-        const unsigned dn = digit_at(k, a.next_shift, a.next_bits);
-        const unsigned c = __umul24(static_cast<unsigned>(o >> a.chunk_shift), a.chunk_mul) >> 16;
-        if constexpr (PEEL == 0) {
-          atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], 1u << ((c & 1u) << 4));
-        } else {
-          const unsigned cell = (c << 8) | dn;
-          const unsigned long long act = __ballot(true);
-          const unsigned l0 = static_cast<unsigned>(__ffsll(static_cast<long long>(act)) - 1);
-          const unsigned cell0 = __builtin_amdgcn_readfirstlane(cell);
-          const unsigned long long g0 = __ballot(cell == cell0);
-          if constexpr (PEEL == 1) first_group = static_cast<unsigned>(__popcll(g0));   // round 0: measure, add one by one
-          unsigned add = 1u;
-          if constexpr (PEEL == 2) {
-            if (cell == cell0) add = lane == l0 ? static_cast<unsigned>(__popcll(g0)) : 0u;
-            const unsigned long long rest = act & ~g0;
-            if (rest) {                                   // wave-uniform
-              const unsigned l1 = static_cast<unsigned>(__ffsll(static_cast<long long>(rest)) - 1);
-              const unsigned cell1 = __builtin_amdgcn_readlane(cell, l1);
-              const unsigned long long g1 = __ballot(cell == cell1);
-              if (cell == cell1) add = lane == l1 ? static_cast<unsigned>(__popcll(g1)) : 0u;
-            }
-          }
-          if (add) atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], add << ((c & 1u) << 4));
-        }
-      }
-      if constexpr (HAS_VAL || kCheckedStores) {
-        // (always true after the per-run check above; kept because the pair kernels schedule measurably better with the
-        // store under this predicate: uint32+uint32 pass 3.6-3.7 ms with it, 3.9-4.0 ms without, same results)
-        const bool inside = static_cast<uint64_t>(o) < a.n;
-        if (inside) kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
-        if constexpr (HAS_VAL) dst[i] = inside ? o : ~static_cast<D>(0);
-        if constexpr (kCheckedStores) { if (!inside) __hip_atomic_fetch_or(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if constexpr (CHAIN && COUNT) if (full || i * BLOCK + tid < tile_count) {
+      const unsigned dn = digit_at(wk[i], a.next_shift, a.next_bits);
+      const unsigned c = __umul24(static_cast<unsigned>(wo[i] >> a.chunk_shift), a.chunk_mul) >> 16;
+      if constexpr (PEEL == 0) {
+        atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], 1u << ((c & 1u) << 4));
       } else {
-        kout[o] = xf_out ? xf_inverse(k, fmo, smo) : k;
+        const unsigned cell = (c << 8) | dn;
+        const unsigned long long act = __ballot(true);
+        const unsigned l0 = static_cast<unsigned>(__ffsll(static_cast<long long>(act)) - 1);
+        const unsigned cell0 = __builtin_amdgcn_readfirstlane(cell);
+        const unsigned long long g0 = __ballot(cell == cell0);
+        if constexpr (PEEL == 1) first_group = static_cast<unsigned>(__popcll(g0));   // round 0: measure, add one by one
+        unsigned add = 1u;
+        if constexpr (PEEL == 2) {
+          if (cell == cell0) add = lane == l0 ? static_cast<unsigned>(__popcll(g0)) : 0u;
+          const unsigned long long rest = act & ~g0;
+          if (rest) {                                   // wave-uniform
+            const unsigned l1 = static_cast<unsigned>(__ffsll(static_cast<long long>(rest)) - 1);
+            const unsigned cell1 = __builtin_amdgcn_readlane(cell, l1);
+            const unsigned long long g1 = __ballot(cell == cell1);
+            if (cell == cell1) add = lane == l1 ? static_cast<unsigned>(__popcll(g1)) : 0u;
+          }
+        }
+        if (add) atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], add << ((c & 1u) << 4));
       }
     }
   };
-  if constexpr (CHAIN && COUNT) {
-    write_round(std::integral_constant<int, 1>{}, 0);
-    if (__builtin_amdgcn_readfirstlane(first_group) >= 8) {   // wave-uniform
+  // The rounds go in batches of WB: within a batch every phase covers all its rounds before the next phase starts.
+#ifndef RS_WOUT_BATCH
+#define RS_WOUT_BATCH 4
+#endif
+  constexpr int WB = RS_WOUT_BATCH < ITEMS ? RS_WOUT_BATCH : ITEMS;
+  static_assert(ITEMS % WB == 0, "write-out batches");
+  bool few = false;                  // few-valued tile: the counting adds go through group leaders (wave-uniform)
 #pragma unroll
-      for (int i = 1; i < ITEMS; ++i) write_round(std::integral_constant<int, 2>{}, i);
-    } else {
+  for (int b0 = 0; b0 < ITEMS; b0 += WB) {
 #pragma unroll
-      for (int i = 1; i < ITEMS; ++i) write_round(std::integral_constant<int, 0>{}, i);
+    for (int i = b0; i < b0 + WB; ++i) {
+      const unsigned sw_i = static_cast<unsigned>(i * BLOCK) ^ (static_cast<unsigned>(i * (BLOCK / kWave)) & 31u);
+      if (full || i * BLOCK + tid < tile_count) wk[i] = stage_k[sw_i ^ sw_t];
     }
-  } else {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) write_round(std::integral_constant<int, 0>{}, i);
+    for (int i = b0; i < b0 + WB; ++i) {
+      const unsigned j = i * BLOCK + tid;
+      if (full || j < tile_count) wo[i] = s.gofs[digit_at(wk[i], a.shift, a.bits)] + j;
+    }
+    if constexpr (CHAIN && COUNT) {
+      int first = b0;
+      if constexpr (full) {
+        if (b0 == 0) {
+          count_round(std::integral_constant<int, 1>{}, 0);
+          few = __builtin_amdgcn_readfirstlane(first_group) >= 8;
+          first = 1;
+        }
+      }
+      if (few) {
+#pragma unroll
+        for (int i = first; i < b0 + WB; ++i) count_round(std::integral_constant<int, 2>{}, i);
+      } else {
+#pragma unroll
+        for (int i = first; i < b0 + WB; ++i) count_round(std::integral_constant<int, 0>{}, i);
+      }
+    }
+    if (xf_out) {                                      // workgroup-uniform: the last launched pass only
+#pragma unroll
+      for (int i = b0; i < b0 + WB; ++i) wk[i] = xf_inverse(wk[i], fmo, smo);
+    }
+#pragma unroll
+    for (int i = b0; i < b0 + WB; ++i) {
+      if (full || i * BLOCK + tid < tile_count) {
+        if constexpr (HAS_VAL || kCheckedStores) {
+          // (always true after the per-run check above; kept because the pair kernels schedule measurably better with the
+          // store under this predicate: uint32+uint32 pass 3.6-3.7 ms with it, 3.9-4.0 ms without, same results)
+          const bool inside = static_cast<uint64_t>(wo[i]) < a.n;
+          if (inside) kout[wo[i]] = wk[i];
+          if constexpr (HAS_VAL) dst[i] = inside ? wo[i] : ~static_cast<D>(0);
+          if constexpr (kCheckedStores) { if (!inside) __hip_atomic_fetch_or(a.error_flag, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        } else {
+          kout[wo[i]] = wk[i];
+        }
+      }
+    }
   }
 #ifdef RS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1052,6 +1164,11 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
       if ((full || j < tile_count) && dst[i] != ~static_cast<D>(0)) vout[dst[i]] = stage_v[j];
     }
   }
+
+  return true;
+  };   // sweep_tile
+  const bool go_on = tile_count == TILE ? sweep_tile(std::true_type{}) : sweep_tile(std::false_type{});
+  if (!go_on) break;
 
   if constexpr (!CHAIN) break;
   else {

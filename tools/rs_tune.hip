@@ -116,6 +116,27 @@ int main(int argc, char** argv) {
       if (!d.empty()) printf("   %-22s median %.2f us  p10 %.2f  p90 %.2f\n", names[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
     }
   }
+  if (f_st && getenv("RS_TUNE_CHAINS")) {   // chain mode: when did each XCD's chain start and finish (stamped tiles only, last stamped pass)
+    std::vector<unsigned long long> st(16 * 4096);
+    f_st(st.data());
+    size_t tile_keys = getenv("RS_TUNE_TILE") ? atoi(getenv("RS_TUNE_TILE")) : 8192; size_t tiles = (n + tile_keys - 1) / tile_keys, cnt = std::min<size_t>(tiles / 64, 4096);
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < cnt; ++i) t0 = std::min(t0, st[i]);
+    const size_t per_chain = (tiles + 7) / 8;
+    for (int c = 0; c < 8; ++c) {
+      unsigned long long lo = ~0ull, hi = 0; std::vector<double> lat;
+      for (size_t i = 0; i < cnt; ++i) {
+        const size_t tile = i * 64;
+        if (tile / per_chain != (size_t)c) continue;
+        lo = std::min(lo, st[i]); hi = std::max(hi, st[7 * 4096 + i]);
+        lat.push_back((double)(long long)(st[7 * 4096 + i] - st[i]) * 0.01);
+      }
+      std::sort(lat.begin(), lat.end());
+      double mean = 0; for (double x : lat) mean += x; if (!lat.empty()) mean /= lat.size();
+      printf("   chain %d: first tile begins %.1f us, last stamped tile written %.1f us; tile latency mean %.2f median %.2f p99 %.2f us\n", c, (lo - t0) * 0.01, (hi - t0) * 0.01,
+             mean, lat.empty() ? 0. : lat[lat.size() / 2], lat.empty() ? 0. : lat[lat.size() * 99 / 100]);
+    }
+  }
   if (f_st) {
     std::vector<unsigned long long> st(16 * 4096);
     f_st(st.data());

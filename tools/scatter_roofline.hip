@@ -65,16 +65,64 @@ __global__ __launch_bounds__(1024) void scatter_kernel_dword(const unsigned* in,
 // Chain order: persistent workgroups, chain = XCC id, tiles of a chain drawn front to back from the chain's own counter (the
 // order of the chain-mode sweep): every run boundary is shared by two tiles of one XCD.
 __device__ inline unsigned xcc_id_() { return static_cast<unsigned>(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20)) & 7u; }
-template <typename T>   // T = unsigned (4-byte lanes) or uint2 (8-byte lanes)
-__global__ __launch_bounds__(1024) void scatter_kernel_chain(const T* in, T* out, unsigned tiles, unsigned streams, unsigned run_e /* elements per run */,
+// The shipped chain-mode sweep's data path with the sorting work taken out: persistent workgroups of BLOCK threads, chain =
+// XCC id, tiles of TILE_BYTES drawn from the chain's counter; every wave brings its segment in by LDS-DMA (16 bytes per lane),
+// the workgroup meets at a barrier, and thread t writes staged elements t, t + BLOCK, ... with one T-sized store each to where
+// a uniform-digit sort would put them (256 streams).  No ranking, no scan, no look-back: what is left is what the memory
+// system gives this access pattern at the sweep's residency (LDS footprint = staging area + `lds` bytes of ballast).
+template <typename T, unsigned BLOCK, unsigned TILE_BYTES, unsigned WGS>
+__global__ __launch_bounds__(BLOCK, (WGS * BLOCK + 255) / 256) void sweep_shape_kernel(const T* in, T* out, unsigned tiles, unsigned run_e, unsigned shift_e, unsigned* tickets) {
+  __shared__ unsigned s_tile;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[TILE_BYTES];
+  extern __shared__ unsigned char lds_ballast[];
+  if (run_e == 0xFFFFFFFFu) lds_ballast[threadIdx.x] = 0;      // (never true: keeps the dynamic LDS allocated)
+  constexpr unsigned tile_e = TILE_BYTES / sizeof(T), per_thread = tile_e / BLOCK, streams = 256;
+  constexpr unsigned seg_bytes = TILE_BYTES / (BLOCK / 64);
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x / 64;
+  const unsigned chain = xcc_id_(), chain_tiles = (tiles + 7) / 8;
+  const unsigned first = chain * chain_tiles, end = min(first + chain_tiles, tiles);
+  const unsigned stream_e = static_cast<unsigned>(static_cast<size_t>(tiles) * tile_e / streams);
+  const unsigned runs_per_stream = tile_e / run_e / streams;
+  const unsigned lg_run = 31 - __builtin_clz(run_e);
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = first + atomicAdd(&tickets[chain * 32], 1u);
+    __syncthreads();
+    const unsigned t = s_tile;
+    if (t >= end) break;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(in) + static_cast<size_t>(t) * TILE_BYTES + wave * seg_bytes + lane * 16;
+    unsigned char* land = stage + wave * seg_bytes;
+#pragma unroll
+    for (unsigned b = 0; b < seg_bytes; b += 1024)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b), (__attribute__((address_space(3))) void*)(land + b), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const T* st = reinterpret_cast<const T*>(stage);
+#pragma unroll
+    for (unsigned i = 0; i < per_thread; ++i) {
+      const unsigned j = i * BLOCK + threadIdx.x;
+      const unsigned r = j >> lg_run, o = j & (run_e - 1);
+      const unsigned sid = r & (streams - 1), k = r >> 8;
+      out[sid * stream_e + ((t * runs_per_stream + k) << lg_run) + o + shift_e] = st[j];
+    }
+    __syncthreads();
+  }
+}
+
+// BLOCK x TILE_BYTES: 1024 x 64 KB is the one-chain sweep's tile; 512 x 32 KB (uint32) / 512 x 64 KB (uint64) with `lds` bytes of
+// dynamic LDS that hold the residency at 3 / 2 workgroups per CU are the shipped chain-mode sweeps' shape.
+template <typename T, unsigned BLOCK = 1024, unsigned TILE_BYTES = 65536, unsigned WGS = 1>   // T = unsigned (4-byte lanes) or uint2 (8-byte lanes)
+__global__ __launch_bounds__(BLOCK, (WGS * BLOCK + 255) / 256) void scatter_kernel_chain(const T* in, T* out, unsigned tiles, unsigned streams, unsigned run_e /* elements per run */,
                                                              unsigned shift_e, unsigned* tickets) {
   __shared__ unsigned s_tile;
-  constexpr unsigned tile_e = 65536 / sizeof(T);
-  constexpr unsigned per_thread = tile_e / 1024;
+  extern __shared__ unsigned char lds_ballast[];
+  if (run_e == 0xFFFFFFFFu) lds_ballast[threadIdx.x] = 0;      // (never true: keeps the dynamic LDS allocated)
+  constexpr unsigned tile_e = TILE_BYTES / sizeof(T);
+  constexpr unsigned per_thread = tile_e / BLOCK;
   const unsigned chain = xcc_id_(), chain_tiles = (tiles + 7) / 8;
   const unsigned first = chain * chain_tiles, end = min(first + chain_tiles, tiles);
   const size_t stream_e = static_cast<size_t>(tiles) * tile_e / streams;
   const unsigned runs_per_stream = tile_e / run_e / streams;
+  const unsigned lg_run = 31 - __builtin_clz(run_e), lg_streams = 31 - __builtin_clz(streams);
   for (;;) {
     if (threadIdx.x == 0) s_tile = first + atomicAdd(&tickets[chain * 32], 1u);
     __syncthreads();
@@ -84,13 +132,15 @@ __global__ __launch_bounds__(1024) void scatter_kernel_chain(const T* in, T* out
     const T* src = in + static_cast<size_t>(t) * tile_e;
     T v[per_thread];
 #pragma unroll
-    for (unsigned i = 0; i < per_thread; ++i) v[i] = src[i * 1024 + threadIdx.x];
+    for (unsigned i = 0; i < per_thread; ++i) v[i] = src[i * BLOCK + threadIdx.x];
 #pragma unroll
     for (unsigned i = 0; i < per_thread; ++i) {
-      const unsigned j = i * 1024 + threadIdx.x;
-      const unsigned r = j / run_e, o = j % run_e;
-      const unsigned st = r % streams, k = r / streams;
-      out[static_cast<size_t>(st) * stream_e + (static_cast<size_t>(t) * runs_per_stream + k) * run_e + o + shift_e] = v[i];
+      const unsigned j = i * BLOCK + threadIdx.x;                  // (run_e and streams are powers of two)
+      const unsigned r = j >> lg_run, o = j & (run_e - 1);
+      const unsigned st = r & (streams - 1), k = r >> lg_streams;
+      // (32-bit element index: the buffers hold at most 2^32 bytes, and a 64-bit address per pending store would spill)
+      const unsigned idx = st * static_cast<unsigned>(stream_e) + ((t * runs_per_stream + k) << lg_run) + o + shift_e;
+      out[idx] = v[i];
     }
   }
 }
@@ -143,5 +193,28 @@ int main(int argc, char** argv) {
       std::sort(ms.begin(), ms.end());
       printf("chain order, %d-byte lanes: streams %4u run %6u B shift %3u B : %.3f ms  %.2f TB/s (read+write)\n", wide ? 8 : 4, c[0], c[1], wide ? (c[2] + 7) / 8 * 8 : c[2], ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
     }
+  // the shipped chain-mode sweeps' shape: 512 threads, 8192-key tiles, 3 (uint32) / 2 (uint64) workgroups per CU held by LDS ballast
+  {
+    const unsigned cus = 256;
+    for (int wide = 0; wide < 2; ++wide) {
+      const unsigned tile_bytes = wide ? 65536 : 32768, tiles_s = bytes / tile_bytes;
+      const unsigned wgs = wide ? 2 : 3, lds = wide ? 8 * 1024 : 11 * 1024;   // + the staging area: 72 / 43 KB per workgroup, as the sweeps
+      const unsigned run_b = tile_bytes / 256;       // 256 streams: the run a uniform digit gets in one tile
+      for (unsigned shift : {0u, 20u}) {
+        std::vector<float> ms;
+        for (int it = 0; it < 7; ++it) {
+          CK(hipMemset(tickets, 0, 8 * 32 * 4));
+          CK(hipEventRecord(e0));
+          if (wide) hipLaunchKernelGGL((sweep_shape_kernel<uint2, 512, 65536, 2>), dim3(cus * wgs), dim3(512), lds, 0, reinterpret_cast<const uint2*>(in), reinterpret_cast<uint2*>(out), tiles_s, run_b / 8, (shift + 7) / 8, tickets);
+          else hipLaunchKernelGGL((sweep_shape_kernel<unsigned, 512, 32768, 3>), dim3(cus * wgs), dim3(512), lds, 0, reinterpret_cast<const unsigned*>(in), reinterpret_cast<unsigned*>(out), tiles_s, run_b / 4, shift / 4, tickets);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          float m; CK(hipEventElapsedTime(&m, e0, e1)); if (it >= 2) ms.push_back(m);
+        }
+        std::sort(ms.begin(), ms.end());
+        printf("the sweep's data path alone (512 threads x %u B tiles, %u workgroups per CU, %u KB LDS each; LDS-DMA in, one store per element out), %d-byte lanes: 256 streams run %u B shift %u B : %.3f ms  %.2f TB/s (read+write)\n",
+               tile_bytes, wgs, (lds + tile_bytes) / 1024, wide ? 8 : 4, run_b, wide ? (shift + 7) / 8 * 8 : shift, ms[ms.size() / 2], 2.0 * bytes / ms[ms.size() / 2] / 1e9);
+      }
+    }
+  }
   return 0;
 }
