@@ -513,7 +513,10 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // The histogram and the zeroed descriptor rows serve both forms.
   bool sweep_chain = chain;
   size_t sweep_tiles = tiles;
-  if (chain && key_bytes == 4 && value_bytes <= 4 && min_bins < 200) {
+#ifndef RS_FEW_VALUED_BINS
+#define RS_FEW_VALUED_BINS 200
+#endif
+  if (chain && key_bytes == 4 && value_bytes <= 4 && min_bins < RS_FEW_VALUED_BINS) {
     sweep_chain = false;
     sweep_tiles = tiles_for(n, key_bytes, value_bytes, false);
   }
