@@ -216,11 +216,14 @@ def bench_strings(eng, m):
     np.cumsum(lens, out=offsets[1:].view(np.int64))
     blob = rng.integers(0, 256, size=int(offsets[-1]), dtype=np.uint8)
     eng.sort_strings_host(blob[: 1 << 16], offsets[:1001].copy())          # warm-up (context, kernels)
-    times = []
+    times, dev_ms = [], []
+    eng.set_profiling(True)
     for _ in range(2):
         t0 = time.perf_counter()
         perm = eng.sort_strings_host(blob, offsets, stable=True)
         times.append(time.perf_counter() - t0)
+        dev_ms.append(sum(eng.profile()))       # HIP events around the device part (between upload and download)
+    eng.set_profiling(False)
     ok_perm = bool((np.bincount(perm.astype(np.int64), minlength=m) == 1).all())
     idx = rng.integers(0, m - 1, size=200_000)
     ok_order = True
@@ -234,8 +237,18 @@ def bench_strings(eng, m):
             break
     sec = min(times)
     moved = int(offsets[-1]) + 8 * (m + 1) + 8 * m
+    # Algorithmic HBM bytes of the first MSD level per string (every string takes part in it; later levels only the
+    # unresolved ones): the chunk kernel reads the offsets (16) and <= 7 string bytes and writes an 8-byte key and a 4-byte
+    # id (35); the stable pair sort of (8-byte chunk key, 4-byte id) is canonical K + 2*8*(K+V) = 200; heads, open flags,
+    # two scans, the gathers and the write-back of the permutation are about 17 four-byte accesses (68): 303 bytes.
+    level0_bytes = 303
+    dev = min(dev_ms) if dev_ms and min(dev_ms) > 0 else None
     return {"strings": m, "ms": sec * 1e3, "mstrings_s": m / sec / 1e6, "host_bytes_per_string": moved / m,
-            "includes": "H2D of blob+offsets, MSD sort, D2H of the permutation", "sorted": ok_order, "checksum": ok_perm}
+            "includes": "H2D of blob+offsets, MSD sort, D2H of the permutation",
+            "device_ms": dev, "device_mstrings_s": m / dev / 1e3 if dev else None,
+            "device_bytes_per_string_level0": level0_bytes,
+            "device_hbm_frac_level0": m * level0_bytes / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS if dev else None,
+            "sorted": ok_order, "checksum": ok_perm}
 
 
 def bench_composite(n):
@@ -286,7 +299,7 @@ def main():
     ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--pairs", default="u32+4,u64+4", help="key type + payload bytes")
     ap.add_argument("--pairs-n", type=int, default=1 << 29)
-    ap.add_argument("--strings", default="10000000", help="string counts for the rs_sort_strings rows")
+    ap.add_argument("--strings", default="10000000,50000000", help="string counts for the rs_sort_strings rows")
     ap.add_argument("--composite-n", type=int, default=10_000_000, help="0 = skip the configs[3] row")
     ap.add_argument("--cpu-n", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")

@@ -1081,6 +1081,8 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
     return blocks;
   };
 
+  const bool prof_strings = c->profiling;
+  if (prof_strings) RS_HIP(c, hipEventRecord(c->ev[0], s));     // the device part: everything between the upload and the download
   size_t m = n;
   uint32_t* cur_pos = nullptr;      // level 0: position j is slot j
   uint32_t* cur_seg = nullptr;      // level 0: one segment
@@ -1099,10 +1101,11 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
       if ((rc = sort_device(c, seg2, val, seg_alt, val_alt, m, 4, 4, RS_XF_NONE, 0, bits)) != RS_OK) { c->profiling = prof; return rc; }
       hipLaunchKernelGGL(rss::chunk_keys_kernel, grid(m), dim3(rss::kBlock), 0, s, d_blob, d_off, ids, val, mm, level, keys);
     }
-    hipLaunchKernelGGL(rss::gather_u32_kernel, grid(m), dim3(rss::kBlock), 0, s, ids, val, mm, ids2);
-    hipLaunchKernelGGL(rss::write_back_kernel, grid(m), dim3(rss::kBlock), 0, s, ids2, cur_pos, mm, perm);
-    hipLaunchKernelGGL(rss::heads_kernel, grid(m), dim3(rss::kBlock), 0, s, keys, level > 0 ? seg2 : nullptr, mm, head);
-    hipLaunchKernelGGL(rss::unresolved_kernel, grid(m), dim3(rss::kBlock), 0, s, keys, head, mm, val_alt /* open */);
+    // the string ids in sorted order: at level 0 ids is the identity, so the sorted payload is already that
+    const uint32_t* ids_sorted = val;
+    if (level > 0) { hipLaunchKernelGGL(rss::gather_u32_kernel, grid(m), dim3(rss::kBlock), 0, s, ids, val, mm, ids2); ids_sorted = ids2; }
+    hipLaunchKernelGGL(rss::write_back_kernel, grid(m), dim3(rss::kBlock), 0, s, ids_sorted, cur_pos, mm, perm);
+    hipLaunchKernelGGL(rss::heads_open_kernel, grid(m), dim3(rss::kBlock), 0, s, keys, level > 0 ? seg2 : nullptr, mm, head, val_alt /* open */);
     scan(head, m, scan_a, true);                       // segment numbers (1-based)
     unsigned blocks = scan(val_alt, m, scan_b, false); // slots of the unresolved
     uint32_t open_count = 0;
@@ -1110,7 +1113,7 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
     RS_HIP(c, hipStreamSynchronize(s));
     if (open_count == 0) break;
     uint32_t* next_pos = cur_pos == pos ? pos2 : pos;
-    hipLaunchKernelGGL(rss::compact_kernel, grid(m), dim3(rss::kBlock), 0, s, val_alt, scan_b, scan_a, ids2, cur_pos, mm,
+    hipLaunchKernelGGL(rss::compact_kernel, grid(m), dim3(rss::kBlock), 0, s, val_alt, scan_b, scan_a, ids_sorted, cur_pos, mm,
                        ids, next_pos, seg);
     cur_pos = next_pos;
     cur_seg = seg;
@@ -1121,6 +1124,7 @@ int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets,
   c->profiling = prof;
   RS_HIP(c, hipGetLastError());
   hipLaunchKernelGGL(rss::widen_kernel, grid(n), dim3(rss::kBlock), 0, s, perm, static_cast<uint32_t>(n), keys);
+  if (prof_strings) { RS_HIP(c, hipEventRecord(c->ev[1], s)); c->ev_count = 2; }   // rs_ctx_get_profile: ms[0] = device time of the string sort
   if ((rc = to_host(c, h_perm, keys, n * 8, 0)) != RS_OK) return rc;
   return finish_host_call(c);
 }

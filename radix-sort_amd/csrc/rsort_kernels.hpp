@@ -687,6 +687,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     }
   }
 
+  bool have_ticket = false;
   for (;;) {   // one tile per trip; kernels without CHAIN leave after the first
   // In the persistent (CHAIN) form everything derived from the thread id is loop-invariant, and the compiler would keep
   // all of it (addresses, segment offsets) in registers across the whole tile: the id is passed through an empty asm
@@ -701,8 +702,10 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #endif
   if (tid == 0) {
     if constexpr (CHAIN) {
-      const unsigned k = atomicAdd(&a.ticket[chain * 32], 1u);
-      s.tile_id = k < chain_end - chain_first ? chain_first + k : kNoTile;
+      if (!have_ticket) {      // (after the first tile the ticket was drawn at the end of the tile before, see there)
+        const unsigned k = atomicAdd(&a.ticket[chain * 32], 1u);
+        s.tile_id = k < chain_end - chain_first ? chain_first + k : kNoTile;
+      }
     } else {
       s.tile_id = draw_tile(a.ticket, tiles_total, a.per_xcd_order != 0);
     }
@@ -960,8 +963,12 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #endif
   // The digit waves stage only their first ITEMS - kLate keys now and the others after the look-back, so that the
   // inclusive prefix -- what the tiles behind this one wait for -- is published that much earlier.
-  constexpr int kLate = CHAIN ? RS_LOOKBACK_FIRST : 0;
-  static_assert(kLate >= 0 && kLate <= ITEMS, "keys staged after the look-back");
+#ifndef RS_LOOKBACK_FIRST_LAST   // the last launched pass (no counting): all of them late -- uint32 last pass 1.93 -> 1.84 ms at N = 2^30;
+#define RS_LOOKBACK_FIRST_LAST 16 // the counting kernels spill with more than 12 and show no gain with 8 or 12
+#endif
+  constexpr int kLateWanted = !CHAIN ? 0 : COUNT ? RS_LOOKBACK_FIRST : RS_LOOKBACK_FIRST_LAST;
+  constexpr int kLate = kLateWanted < ITEMS ? kLateWanted : ITEMS;
+  static_assert(kLate >= 0, "keys staged after the look-back");
   if (kLate == 0 || tid >= kRadix) stage_keys(std::integral_constant<int, 0>{}, std::integral_constant<int, ITEMS>{});
   else stage_keys(std::integral_constant<int, 0>{}, std::integral_constant<int, ITEMS - kLate>{});
   RS_STAMP(5);
@@ -1165,10 +1172,24 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     }
   }
 
+#ifndef RS_EARLY_TICKET
+#define RS_EARLY_TICKET 0
+#endif
+  if constexpr (CHAIN && RS_EARLY_TICKET) {
+    // Measured and left off: the next tile's ticket drawn now that this tile's stores are issued, so that the round trip of
+    // the atomic (about 0.5 us) overlaps the end of the tile instead of opening the next one.  uint32 N = 2^30: 8.77 ->
+    // 8.90 ms -- a ticket that exists before its workgroup is free lengthens the wait of every tile behind it, as the
+    // prefetching variants did.  (tile_id was last read before this tile's barriers.)
+    if (tid == 0) {
+      const unsigned k = atomicAdd(&a.ticket[chain * 32], 1u);
+      s.tile_id = k < chain_end - chain_first ? chain_first + k : kNoTile;
+    }
+  }
   return true;
   };   // sweep_tile
   const bool go_on = tile_count == TILE ? sweep_tile(std::true_type{}) : sweep_tile(std::false_type{});
   if (!go_on) break;
+  have_ticket = RS_EARLY_TICKET != 0;
 
   if constexpr (!CHAIN) break;
   else {

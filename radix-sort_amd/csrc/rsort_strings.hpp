@@ -76,6 +76,19 @@ __global__ void unresolved_kernel(const uint64_t* keys, const uint32_t* head, ui
   }
 }
 
+// heads_kernel and unresolved_kernel in one launch: a thread looks at its key, its left and its right neighbour
+__global__ void heads_open_kernel(const uint64_t* keys, const uint32_t* seg, uint32_t m, uint32_t* head, uint32_t* open) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) {
+    const uint64_t k = keys[j];
+    const uint32_t sg = seg ? seg[j] : 0u;
+    const bool h = j == 0 || k != keys[j - 1] || (seg && sg != seg[j - 1]);
+    const bool next_h = j + 1 == m || k != keys[j + 1] || (seg && sg != seg[j + 1]);
+    head[j] = h ? 1u : 0u;
+    open[j] = ((k & 0xFF) == kChunkBytes && !(h && next_h)) ? 1u : 0u;
+  }
+}
+
 __global__ void compact_kernel(const uint32_t* open, const uint32_t* open_excl, const uint32_t* head_incl,
                                const uint32_t* ids, const uint32_t* pos, uint32_t m, uint32_t* ids_out,
                                uint32_t* pos_out, uint32_t* seg_out) {
