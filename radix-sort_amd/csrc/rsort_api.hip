@@ -219,7 +219,12 @@ void launch_sweep(const rsk::SweepArgs& a, size_t tiles, bool atomic_rank, bool 
     if (chain) {   // persistent workgroups, one chain of tiles per XCD (only with the returning-add ranking)
       constexpr int kBlockC = sweep_block(static_cast<int>(sizeof(K)), kVal, true);
       constexpr int kItemsC = sweep_items(static_cast<int>(sizeof(K)), kVal, true);
-      constexpr int kMinBlocksC = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_CHAIN_MIN_BLOCKS : RS_MIN_BLOCKS_WIDE;
+      // (wide: two workgroups per CU by LDS, so the register allocator is held to the 128 registers that go with it;
+      // the pair kernel with counting took 144 when left alone, i.e. one workgroup per CU)
+#ifndef RS_CHAIN_MIN_BLOCKS_WIDE
+#define RS_CHAIN_MIN_BLOCKS_WIDE 2
+#endif
+      constexpr int kMinBlocksC = narrow_geometry(static_cast<int>(sizeof(K)), kVal) ? RS_CHAIN_MIN_BLOCKS : RS_CHAIN_MIN_BLOCKS_WIDE;
       auto launch = [&](auto kernel) {
         static const int per_cu = [&] {      // resident workgroups per CU (registers, LDS, wave slots)
           int nb = 0;
@@ -516,7 +521,8 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
 #ifndef RS_FEW_VALUED_BINS
 #define RS_FEW_VALUED_BINS 200
 #endif
-  if (chain && key_bytes == 4 && value_bytes <= 4 && min_bins < RS_FEW_VALUED_BINS) {
+  static const int few_bins = [] { const char* e = std::getenv("RSORT_FEW_VALUED_BINS"); return e ? std::atoi(e) : RS_FEW_VALUED_BINS; }();   // (A/B timing)
+  if (chain && key_bytes == 4 && value_bytes <= 4 && min_bins < few_bins) {
     sweep_chain = false;
     sweep_tiles = tiles_for(n, key_bytes, value_bytes, false);
   }

@@ -507,20 +507,42 @@ template <bool WIDE = false> __device__ __forceinline__ unsigned rank_add_peeled
 // word, and only one run can be peeled).  The first lane of every run adds the run's length; the others take what it
 // got plus their distance from it.  Two runs of one digit in a round (A B A) are two adds on one cell in one instruction,
 // served in lane order like any other pair.  Correct for any digits -- with 64 runs it is rank_add with more work.
-// Call with the active lanes only, which must be a prefix of the wave (they are: lane l holds key seg + i * 64 + l).
-template <bool WIDE = false> __device__ __forceinline__ unsigned rank_add_runs(unsigned* cells, unsigned d) {
+// Call with all 64 lanes active (full tiles; the probe's run-head rounds).
+// The digit of the lane below across the whole wave (DPP wave_shr:1, one instruction, no LDS); lane 0 reads ~d, i.e. a head.
+__device__ __forceinline__ unsigned digit_of_lane_below(unsigned d) {
+  return static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(~d), static_cast<int>(d), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+// N successive rounds at once, each phase over all of them in straight-line code: the head masks (vector and scalar
+// arithmetic only), then the N returning adds of the heads, then the N broadcasts of the heads' answers -- N LDS
+// operations in flight per phase instead of three dependent LDS round trips per round.  All 64 lanes must be active.
+template <bool WIDE, int N>
+__device__ __forceinline__ void rank_add_runs_n(unsigned* cells, const unsigned (&d)[N], unsigned (&r)[N]) {
   const unsigned lane = lane_id();
-  const unsigned prev = __shfl_up(d, 1, kWave);                      // lane 0: its own digit
-  const unsigned long long act = __ballot(true);
-  const unsigned long long heads = __ballot(lane == 0 || prev != d);   // active lanes only, lane 0 always
-  const unsigned long long upto = heads & (~0ull >> (63u - lane));    // heads at or below this lane: never empty
-  const unsigned head_lane = 63u - static_cast<unsigned>(__clzll(static_cast<long long>(upto)));
-  const unsigned long long above = lane == 63u ? 0ull : heads >> (lane + 1u);
-  const unsigned run_end = above ? lane + static_cast<unsigned>(__ffsll(static_cast<long long>(above)))
-                                 : static_cast<unsigned>(__popcll(act));      // next head, or one past the last active lane
-  unsigned got = 0;
-  if (head_lane == lane) got = cell_add<WIDE>(cells, d, run_end - lane);
-  return static_cast<unsigned>(__shfl(static_cast<int>(got), static_cast<int>(head_lane), kWave)) + (lane - head_lane);
+  unsigned head_lane[N], got[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const unsigned long long heads = __ballot(digit_of_lane_below(d[j]) != d[j]);      // lane 0 always
+    const unsigned long long upto = heads & (~0ull >> (63u - lane));                   // heads at or below this lane: never empty
+    head_lane[j] = 63u - static_cast<unsigned>(__clzll(static_cast<long long>(upto)));
+    const unsigned long long above = lane == 63u ? 0ull : heads >> (lane + 1u);
+    const unsigned run_end = above ? lane + static_cast<unsigned>(__ffsll(static_cast<long long>(above))) : 64u;   // next head, or one past the wave
+    got[j] = run_end - lane;                                                           // the run's length, where this lane is a head
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const unsigned len = got[j];
+    got[j] = 0;
+    if (head_lane[j] == lane) got[j] = cell_add<WIDE>(cells, d[j], len);
+  }
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    r[j] = static_cast<unsigned>(__shfl(static_cast<int>(got[j]), static_cast<int>(head_lane[j]), kWave)) + (lane - head_lane[j]);
+}
+template <bool WIDE = false> __device__ __forceinline__ unsigned rank_add_runs(unsigned* cells, unsigned d) {
+  const unsigned dd[1] = {d};
+  unsigned rr[1];
+  rank_add_runs_n<WIDE, 1>(cells, dd, rr);
+  return rr[0];
 }
 
 // Probe for the ranking shortcut, on exactly the forms the kernels run: both cell layouts (WIDE = false in 1024-thread
@@ -801,7 +823,10 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   // add without any wait in the instruction stream: 2 x ITEMS LDS operations stay in flight and no
   // register dependency links the rounds.
   unsigned short rank[ITEMS];
-  unsigned char dig[ITEMS];
+  // 8-byte kernels keep every key's digit from the ranking to the staging (they have the registers); 4-byte kernels
+  // extract it again there: one instruction against a register per key, which the 64-register kernels do not have
+  constexpr bool KEEP_DIG = sizeof(K) == 8;
+  unsigned char dig[KEEP_DIG ? ITEMS : 1];
   unsigned* wwords = reinterpret_cast<unsigned*>(s.whist[wave]);   // the wave's cells as 32-bit words
   static_assert(RANK_BY_LDS_ATOMIC || !CHAIN, "the ballot form knows the 16-bit cells only");
   if constexpr (RANK_BY_LDS_ATOMIC) {
@@ -818,17 +843,18 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     // A wave whose rounds are a few CONTIGUOUS runs of equal digits (an ordered input whose neighbours share a digit: a
     // float ramp repeats every value 8-128 times) ranks all its rounds by run heads; peeling would take out one run only,
     // and often none (no run reaches 16 lanes).  Looked at once per tile, on the wave's first round, so that random
-    // digits pay a third of an instruction per key for it: one DPP move (the digit of the lane below, inside rows of 16
-    // lanes), one compare, one count.  Row starts count as heads, so one run over the whole wave reads 4 -- that case
-    // stays with the peel, its cheapest form -- and random digits read about 64.
+    // digits pay a third of an instruction per key for it: one DPP move (the digit of the lane below, across the wave),
+    // one compare, one count.  One run over the whole wave reads 1 -- that case stays with the peel, its cheapest form --
+    // and random digits read about 64.  (The first version looked inside rows of 16 lanes and counted the row starts as
+    // heads: two ALIGNED runs of 32 then read 4 like one run, were peeled, and the second run's 32 lanes queued on one
+    // word -- a sorted input with every value 32 times swept at 2.65 ms per pass against 1.88 with distinct values.)
     bool runs_group = false;
     bool special = false;      // some group of four rounds wants the peeled or the run-head form (wave-uniform)
     bool peel_group[ITEMS / 4];
     if constexpr (full) {      // (the ragged last tile ranks by plain adds: correct for any digits, and it is one tile)
       const unsigned d = digit_at(key[0], a.shift, a.bits);
-      const unsigned below = static_cast<unsigned>(__builtin_amdgcn_update_dpp(static_cast<int>(~d), static_cast<int>(d), 0x111 /* row_shr:1 */, 0xF, 0xF, false));
-      const unsigned heads = static_cast<unsigned>(__popcll(__ballot(below != d)));
-      runs_group = heads > 4 && heads <= 20;
+      const unsigned heads = static_cast<unsigned>(__popcll(__ballot(digit_of_lane_below(d) != d)));   // runs in the wave's first round
+      runs_group = heads > 1 && heads <= 20;
       special = runs_group;
 #pragma unroll
       for (int g = 0; g < ITEMS; g += 4) {
@@ -846,7 +872,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
       for (int i = 0; i < ITEMS; ++i) {
         unsigned d = digit_at(key[i], a.shift, a.bits);
-        dig[i] = static_cast<unsigned char>(d);
+        if constexpr (KEEP_DIG) dig[i] = static_cast<unsigned char>(d);
         unsigned r = 0;
         if (full || (seg + i * kWave) < tile_count) r = rank_add<WIDE_CELLS>(wwords, d);
         rank[i] = static_cast<unsigned short>(r);
@@ -855,24 +881,32 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
       for (int g = 0; g < ITEMS; g += 4) {
         if (runs_group) {
+          // (four rounds at a time where the registers allow it; the 1024-thread kernels, held to 64 registers, take two)
+          constexpr int RB = BLOCK >= 1024 ? 2 : 4;
 #pragma unroll
-          for (int i = g; i < g + 4; ++i) {
-            unsigned d = digit_at(key[i], a.shift, a.bits);
-            dig[i] = static_cast<unsigned char>(d);
-            rank[i] = static_cast<unsigned short>(rank_add_runs<WIDE_CELLS>(wwords, d));
+          for (int h = g; h < g + 4; h += RB) {
+            unsigned dd[RB], rr[RB];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+              dd[j] = digit_at(key[h + j], a.shift, a.bits);
+              if constexpr (KEEP_DIG) dig[h + j] = static_cast<unsigned char>(dd[j]);
+            }
+            rank_add_runs_n<WIDE_CELLS, RB>(wwords, dd, rr);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) rank[h + j] = static_cast<unsigned short>(rr[j]);
           }
         } else if (peel_group[g / 4]) {
 #pragma unroll
           for (int i = g; i < g + 4; ++i) {
             unsigned d = digit_at(key[i], a.shift, a.bits);
-            dig[i] = static_cast<unsigned char>(d);
+            if constexpr (KEEP_DIG) dig[i] = static_cast<unsigned char>(d);
             rank[i] = static_cast<unsigned short>(rank_add_peeled<WIDE_CELLS>(wwords, d));
           }
         } else {
 #pragma unroll
           for (int i = g; i < g + 4; ++i) {
             unsigned d = digit_at(key[i], a.shift, a.bits);
-            dig[i] = static_cast<unsigned char>(d);
+            if constexpr (KEEP_DIG) dig[i] = static_cast<unsigned char>(d);
             rank[i] = static_cast<unsigned short>(rank_add<WIDE_CELLS>(wwords, d));
           }
         }
@@ -882,7 +916,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       unsigned d = digit_at(key[i], a.shift, a.bits);
-      dig[i] = static_cast<unsigned char>(d);
+      if constexpr (KEEP_DIG) dig[i] = static_cast<unsigned char>(d);
       unsigned dlo, dhi;
       differ_mask(d, dlo, dhi);
       unsigned plo = ~dlo, phi = ~dhi;                   // peers: lanes holding the same digit
@@ -952,7 +986,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   // compiler must assume to alias the next read, waited for the read before it)
   K* stage_k = reinterpret_cast<K*>(s.stage);
 #pragma unroll
-  for (int i = 0; i < ITEMS; ++i) rank[i] = static_cast<unsigned short>(s.whist[wave][dig[i]] + rank[i]);
+  for (int i = 0; i < ITEMS; ++i) rank[i] = static_cast<unsigned short>(s.whist[wave][KEEP_DIG ? static_cast<unsigned>(dig[i]) : digit_at(key[i], a.shift, a.bits)] + rank[i]);
   auto stage_keys = [&](auto from_tag, auto to_tag) {
 #pragma unroll
     for (int i = decltype(from_tag)::value; i < decltype(to_tag)::value; ++i)

@@ -26,6 +26,7 @@ template <typename K> __global__ void gen(K* k, uint64_t n, int shape) {
     uint64_t v;
     if (shape == 0) v = mix(i);
     else if (shape == 4) v = mix(mix(i) & 255);
+    else if (shape == 5) v = (i >> 5) * (step << 5);      // sorted, every value 32 times (what a float ramp looks like)
     else {
       uint64_t j = i;
       if (shape == 2) j = n - 1 - i;
@@ -57,7 +58,7 @@ int main(int argc, char** argv) {
   auto f_err = (const char* (*)(const rs_ctx*))dlsym(h, "rs_last_error");
   int kb = atoi(argv[2]);
   uint64_t n = strtoull(argv[3], 0, 10); if (n <= 40) n = 1ull << n;
-  int shape = !strcmp(argv[4], "random") ? 0 : !strcmp(argv[4], "sorted") ? 1 : !strcmp(argv[4], "reverse") ? 2 : !strcmp(argv[4], "nearly") ? 3 : 4;
+  int shape = !strcmp(argv[4], "random") ? 0 : !strcmp(argv[4], "sorted") ? 1 : !strcmp(argv[4], "reverse") ? 2 : !strcmp(argv[4], "nearly") ? 3 : !strcmp(argv[4], "ramp32") ? 5 : 4;
   int iters = argc > 5 ? atoi(argv[5]) : 5;
   int vb = argc > 6 ? atoi(argv[6]) : 0;
   rs_ctx* c = nullptr;
