@@ -246,3 +246,58 @@ def test_concurrent_sorts_on_two_contexts(oracle):
         for t in threads:
             t.join()
         assert not errors, errors
+
+
+@pytest.mark.parametrize("switches", ["RSORT_CHAIN_MIN_TILES=2", "RSORT_CHAIN_MIN_TILES=2 RSORT_FEW_VALUED_BINS=0",
+                                      "RSORT_CHAIN_MIN_TILES=2 RSORT_FORCE_WIDE=1"])
+def test_chain_mode_at_test_sizes(oracle, switches):
+    """The chain-mode sweeps (one chain of tiles per XCD, persistent workgroups, next-pass counting) serve sorts of at
+    least 4096 tiles in the product -- 33 M four-byte keys, more than a parity test should move through the CPU oracle.
+    RSORT_CHAIN_MIN_TILES lowers that bound (a child process: the switches are read once per process), so the same
+    kernels run here on 2 to a few hundred tiles: chains of one tile, empty trailing chains, ragged last tiles, every key
+    type that uses them, few-valued keys forced down them (RSORT_FEW_VALUED_BINS=0), sorted inputs whose values repeat
+    (run-head ranking with aligned and unaligned runs), 8-byte descriptors, and the 8-byte-key / 4-byte-payload pairs."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import radix_sort_amd as rs
+from radix_sort_amd import shapes
+from cpu_checkers import load_oracle
+orc = load_oracle(); eng = rs.Engine(0); eng.set_precheck(False)
+sizes = (2 * 8192, 16385, 8 * 8192 + 5, 300001, (1 << 21) + 77)
+for name in ("u32", "i32", "f32", "u64", "i64", "f64"):
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    for shape in ("randomized", "duplicates", "sorted", "nearly_sorted", "reverse_sorted"):
+        for n in sizes:
+            v = shapes.generate(name, n, shape)
+            assert eng.sort_keys_host(v, xf).tobytes() == orc.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
+    for rep in (32, 17, 3):                       # sorted, every value `rep` times: runs of equal digits in every pass
+        for n in (300001, (1 << 21) + 77):
+            base = np.sort(shapes.generate(name, n // rep + 1, "randomized"))
+            v = np.repeat(base, rep)[:n].copy()
+            if xf == 2:
+                v = v[~np.isnan(v)]
+                v = np.sort(v)
+            got = eng.sort_keys_host(v, xf)
+            assert got.tobytes() == orc.sort_keys(v, xf, mt=True).tobytes(), (name, "repeat", rep, n)
+for kname in ("u64", "i64"):
+    dt, kb, xf = shapes.KEY_TYPES[kname]
+    for shape in ("randomized", "duplicates", "nearly_sorted"):
+        for n in (16385, 300001, (1 << 20) + 3):
+            k = shapes.generate(kname, n, shape)
+            gk, gp = eng.sort_pairs_host(k, np.arange(n, dtype=np.uint32))      # 4-byte payload: the pair shape that runs in chain mode
+            wk, wp = orc.sort_pairs(k, xf, mt=True)
+            assert gk.tobytes() == wk.tobytes() and (gp == wp).all(), (kname, shape, n)
+print("CHAIN OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for sw in switches.split():
+        name, value = sw.split("=")
+        env[name] = value
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHAIN OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
