@@ -666,7 +666,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #ifdef RS_NO_WIDE_CELLS
   constexpr bool WIDE_CELLS = false;
 #else
-  constexpr bool WIDE_CELLS = CHAIN;     // the 512-thread chain kernels have the LDS for one word per digit and wave
+  constexpr bool WIDE_CELLS = CHAIN && BLOCK <= 512;     // the 512-thread chain kernels have the LDS for one word per digit and wave
 #endif
   using Smem = SweepSmem<K, V, D, BLOCK, ITEMS, WIDE_CELLS>;
   using Cell = typename Smem::Cell;

@@ -108,6 +108,50 @@ __global__ __launch_bounds__(BLOCK, (WGS * BLOCK + 255) / 256) void sweep_shape_
   }
 }
 
+// The same with FOUR consecutive staged 4-byte elements per lane and ONE 16-byte store at a 4-byte aligned address (runs are
+// multiples of four elements here, so a lane's four elements always share a run): does the write side of a uint32 sweep
+// get cheaper when the address unit sees a quarter of the store instructions?
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <unsigned BLOCK, unsigned TILE_BYTES, unsigned WGS>
+__global__ __launch_bounds__(BLOCK, (WGS * BLOCK + 255) / 256) void sweep_shape_kernel_x4(const unsigned* in, unsigned* out, unsigned tiles, unsigned run_e, unsigned shift_e, unsigned* tickets) {
+  __shared__ unsigned s_tile;
+  __shared__ __attribute__((aligned(16))) unsigned char stage[TILE_BYTES];
+  extern __shared__ unsigned char lds_ballast[];
+  if (run_e == 0xFFFFFFFFu) lds_ballast[threadIdx.x] = 0;
+  constexpr unsigned tile_e = TILE_BYTES / 4, per_thread = tile_e / BLOCK / 4, streams = 256;
+  constexpr unsigned seg_bytes = TILE_BYTES / (BLOCK / 64);
+  const unsigned lane = threadIdx.x & 63, wave = threadIdx.x / 64;
+  const unsigned chain = xcc_id_(), chain_tiles = (tiles + 7) / 8;
+  const unsigned first = chain * chain_tiles, end = min(first + chain_tiles, tiles);
+  const unsigned stream_e = static_cast<unsigned>(static_cast<size_t>(tiles) * tile_e / streams);
+  const unsigned runs_per_stream = tile_e / run_e / streams;
+  const unsigned lg_run = 31 - __builtin_clz(run_e);
+  for (;;) {
+    if (threadIdx.x == 0) s_tile = first + atomicAdd(&tickets[chain * 32], 1u);
+    __syncthreads();
+    const unsigned t = s_tile;
+    if (t >= end) break;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(in) + static_cast<size_t>(t) * TILE_BYTES + wave * seg_bytes + lane * 16;
+    unsigned char* land = stage + wave * seg_bytes;
+#pragma unroll
+    for (unsigned b = 0; b < seg_bytes; b += 1024)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + b), (__attribute__((address_space(3))) void*)(land + b), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const u32x4* st = reinterpret_cast<const u32x4*>(stage);
+#pragma unroll
+    for (unsigned i = 0; i < per_thread; ++i) {
+      const unsigned q = i * BLOCK + threadIdx.x, j = q * 4;
+      const unsigned r = j >> lg_run, o = j & (run_e - 1);
+      const unsigned sid = r & (streams - 1), k = r >> 8;
+      unsigned* dst = out + (sid * stream_e + ((t * runs_per_stream + k) << lg_run) + o + shift_e);
+      const u32x4 v = st[q];
+      asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+    }
+    __syncthreads();
+  }
+}
+
 // BLOCK x TILE_BYTES: 1024 x 64 KB is the one-chain sweep's tile; 512 x 32 KB (uint32) / 512 x 64 KB (uint64) with `lds` bytes of
 // dynamic LDS that hold the residency at 3 / 2 workgroups per CU are the shipped chain-mode sweeps' shape.
 template <typename T, unsigned BLOCK = 1024, unsigned TILE_BYTES = 65536, unsigned WGS = 1>   // T = unsigned (4-byte lanes) or uint2 (8-byte lanes)
@@ -205,7 +249,8 @@ int main(int argc, char** argv) {
         for (int it = 0; it < 7; ++it) {
           CK(hipMemset(tickets, 0, 8 * 32 * 4));
           CK(hipEventRecord(e0));
-          if (wide) hipLaunchKernelGGL((sweep_shape_kernel<uint2, 512, 65536, 2>), dim3(cus * wgs), dim3(512), lds, 0, reinterpret_cast<const uint2*>(in), reinterpret_cast<uint2*>(out), tiles_s, run_b / 8, (shift + 7) / 8, tickets);
+          if (!wide && getenv("SCATTER_X4")) hipLaunchKernelGGL((sweep_shape_kernel_x4<512, 32768, 3>), dim3(cus * wgs), dim3(512), lds, 0, reinterpret_cast<const unsigned*>(in), reinterpret_cast<unsigned*>(out), tiles_s, run_b / 4, shift / 4, tickets);
+          else if (wide) hipLaunchKernelGGL((sweep_shape_kernel<uint2, 512, 65536, 2>), dim3(cus * wgs), dim3(512), lds, 0, reinterpret_cast<const uint2*>(in), reinterpret_cast<uint2*>(out), tiles_s, run_b / 8, (shift + 7) / 8, tickets);
           else hipLaunchKernelGGL((sweep_shape_kernel<unsigned, 512, 32768, 3>), dim3(cus * wgs), dim3(512), lds, 0, reinterpret_cast<const unsigned*>(in), reinterpret_cast<unsigned*>(out), tiles_s, run_b / 4, shift / 4, tickets);
           CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
           float m; CK(hipEventElapsedTime(&m, e0, e1)); if (it >= 2) ms.push_back(m);
