@@ -454,14 +454,21 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   if (chain) {
     // chains of U8 << r tiles, r such that positions >> (log2(tile) + r) stay below 256: the chain of an output position is
     // then one shift, one 24-bit multiply and one shift (checked here for every value the kernel can meet)
+    // (tile = odd * 2^q keys: positions are counted in units of 2^(q + r) keys, a chain is u8 units with u8 a multiple of
+    // `odd`, so that every chain is a whole number of tiles; odd = 1 for the power-of-two tiles of the shipped geometry)
+    const size_t tk = tile_keys(key_bytes, value_bytes, true);
+    unsigned q = 0;
+    while (((tk >> q) & 1u) == 0) ++q;
+    const unsigned odd = static_cast<unsigned>(tk >> q);
+    const size_t units0 = (n + (size_t(1) << q) - 1) >> q;
     unsigned r = 0;
-    while (((tiles + (size_t(1) << r) - 1) >> r) > 255) ++r;
-    const unsigned u_max = static_cast<unsigned>((tiles + (size_t(1) << r) - 1) >> r);
-    const unsigned u8 = (u_max + rsk::kXcds - 1) / rsk::kXcds;
-    chain_tiles = u8 << r;
-    unsigned tile_log2 = 0;
-    while ((size_t(1) << tile_log2) < tile_keys(key_bytes, value_bytes, true)) ++tile_log2;
-    chunk_shift = tile_log2 + r;
+    while (((units0 + (size_t(1) << r) - 1) >> r) > 255 - rsk::kXcds * odd) ++r;
+    const unsigned u_max = static_cast<unsigned>((units0 + (size_t(1) << r) - 1) >> r);
+    unsigned u8 = (u_max + rsk::kXcds - 1) / rsk::kXcds;
+    u8 = (u8 + odd - 1) / odd * odd;
+    if ((static_cast<size_t>(u8) << r) % odd != 0) return fail(c, RS_ERR_KERNEL, "chain split arithmetic");
+    chain_tiles = static_cast<unsigned>((static_cast<size_t>(u8) << r) / odd);
+    chunk_shift = q + r;
     chunk_mul = (65536u + u8 - 1) / u8;
     for (unsigned u = 0; u < u_max; ++u)
       if (((u * chunk_mul) >> 16) != u / u8 || u / u8 >= rsk::kXcds) return fail(c, RS_ERR_KERNEL, "chain split arithmetic");
