@@ -666,7 +666,9 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #ifdef RS_NO_WIDE_CELLS
   constexpr bool WIDE_CELLS = false;
 #else
-  constexpr bool WIDE_CELLS = CHAIN && BLOCK <= 512;     // the 512-thread chain kernels have the LDS for one word per digit and wave
+  // (the 512-thread chain kernels have the LDS for one word per digit and wave -- except 8-byte keys with 8-byte offsets,
+  // n > 2^30: their offset tables are 2 KB larger, and with 4 KB more of cells two workgroups no longer fit a CU)
+  constexpr bool WIDE_CELLS = CHAIN && BLOCK <= 512 && !(sizeof(K) == 8 && sizeof(D) == 8);
 #endif
   using Smem = SweepSmem<K, V, D, BLOCK, ITEMS, WIDE_CELLS>;
   using Cell = typename Smem::Cell;
