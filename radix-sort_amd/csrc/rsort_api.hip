@@ -479,7 +479,14 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // counts, bases and tickets; NOT the error word behind them: it keeps a fault until check_kernel_error has read it
   RS_HIP(c, hipMemsetAsync(ctrl + kCtrlHist, 0, kCtrlMidDesc - kCtrlHist + (mid ? tiles * 256 * 4 : 0), s));
   if (chain) RS_HIP(c, hipMemsetAsync(ctrl + kCtrlChainHist, 0, kCtrlBytesChain - kCtrlChainHist, s));
-  if (!mid) RS_HIP(c, hipMemsetAsync(desc, 0, tiles * 256 * (wide ? 8 : 4), s));   // the rows this sort uses, not the whole reservation
+  // Chain mode keeps 4-byte descriptors and offsets up to 2^32 keys: a descriptor holds a count inside ONE chain (at most an
+  // eighth of the keys plus a tile, below 2^30), and output offsets below 2^32 fit the 4-byte tables.  The one-chain
+  // kernels' descriptors hold counts over the whole array and need the 8-byte form from 2^30 keys on.
+  const bool wide_chain = force_wide || n >= (size_t(1) << 32);
+  // (the rows this sort uses, not the whole reservation; should the few-valued rule below send a chain-mode sort of more
+  // than 2^30 keys down the one-chain kernels, their 8-byte rows of 16384-key tiles take exactly the bytes of the 4-byte rows
+  // of 8192-key tiles cleared here)
+  if (!mid) RS_HIP(c, hipMemsetAsync(desc, 0, tiles * 256 * ((chain ? wide_chain : wide) ? 8 : 4), s));
 
   auto* chain_hist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlChainHist);
   auto* next_cnt = reinterpret_cast<unsigned long long*>(ctrl + kCtrlNextCnt);
@@ -536,7 +543,9 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
 
   void* kin = keys; void* kout = alt_keys;
   void* vin = vals; void* vout = alt_vals;
-  const SweepLaunch launch{sweep_tiles, key_bytes, value_bytes, wide, c->rank_by_lds_atomic, sweep_chain, static_cast<unsigned>(c->cus), s};
+  if (chain && !sweep_chain && wide && !wide_chain && sweep_tiles * 256 * 8 > tiles * 256 * 4)
+    return fail(c, RS_ERR_KERNEL, "descriptor rows of the one-chain fallback");      // (cannot happen: 16384- against 8192-key tiles)
+  const SweepLaunch launch{sweep_tiles, key_bytes, value_bytes, sweep_chain ? wide_chain : wide, c->rank_by_lds_atomic, sweep_chain, static_cast<unsigned>(c->cus), s};
   for (int done = 0; done < n_live; ++done) {
     const int p = live[done];
     rsk::SweepArgs a{};

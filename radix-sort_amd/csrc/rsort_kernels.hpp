@@ -342,7 +342,8 @@ __global__ __launch_bounds__(kRadix) void digit_scan_kernel(unsigned long long* 
 template <typename D> struct Desc;
 template <> struct Desc<uint32_t> {
   static constexpr int kShift = 30;
-  static constexpr uint32_t kValueMask = (1u << 30) - 1u;   // n <= 2^30 (see host dispatch)
+  static constexpr uint32_t kValueMask = (1u << 30) - 1u;   // counts up to 2^30 - 1: n <= 2^30 for one chain over all tiles; n < 2^32 in chain
+                                                            // mode, where a word counts inside one of eight chains (see host dispatch)
 };
 template <> struct Desc<uint64_t> {
   static constexpr int kShift = 62;
