@@ -301,3 +301,35 @@ print("CHAIN OK")
         env[name] = value
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CHAIN OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_more_than_2_30_keys_on_the_device():
+    """Sorts of more than 2^30 keys: chain mode with 4-byte descriptors (a descriptor counts inside one chain), and -- few-valued
+    keys -- the one-chain kernels with 8-byte descriptors.  Too large for the CPU oracle: checked on the device for order,
+    key sum and the count of every value of the few-valued input (the size-independent properties of a sort)."""
+    import torch
+    import radix_sort_amd as rs
+    n = (1 << 30) + 12345
+    eng = rs.Engine(0)
+    eng.set_precheck(False)
+    try:
+        for few in (False, True):
+            g = torch.Generator(device="cuda"); g.manual_seed(3)
+            keys = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, device="cuda", generator=g)
+            if few:
+                keys = (keys >> 24) * 65537                      # 256 values
+            want_sum = int(keys.sum(dtype=torch.int64).item())
+            want_hist = torch.bincount(((keys >> 24) + 128).to(torch.int64), minlength=256) if few else None
+            torch.cuda.synchronize()
+            eng.sort_keys_(keys, 1)                               # signed order
+            eng.synchronize()
+            assert int(keys.sum(dtype=torch.int64).item()) == want_sum
+            step = 1 << 27
+            for lo in range(0, n - 1, step):
+                hi = min(lo + step + 1, n)
+                assert bool((keys[lo + 1:hi] >= keys[lo:hi - 1]).all().item()), (few, lo)
+            if few:
+                assert bool((torch.bincount(((keys >> 24) + 128).to(torch.int64), minlength=256) == want_hist).all().item())
+            del keys
+    finally:
+        eng.close()
