@@ -104,6 +104,7 @@ struct rs_ctx {
   int cus = 256;                     // compute units of the device (persistent grids: 2 workgroups each)
   char* static_scratch = nullptr;    // this device's copy of rs_static_scratch (rs_sort_keys_device_noalloc)
   bool static_used = false;          // a sort has used it since its error word was last read
+  int hist_copy = 0;                 // the copy of the digit counts in `ctrl` that is zero now (kCtrlHist1)
   unsigned* pinned_flags = nullptr;  // two pinned host words the error words are fetched into (a pageable 4-byte copy costs 20 us)
   bool host_call = false;            // sort_device runs inside a host-buffer entry point (which waits for the device anyway)
   bool profiling = false;
@@ -124,11 +125,17 @@ namespace {
 // sorts of at most kAlwaysSweepTiles tiles (256 KB); larger sorts use the separate descriptor buffer.
 constexpr size_t kCtrlError = 0;
 constexpr size_t kCtrlHist = 64;
-constexpr size_t kCtrlBase = kCtrlHist + kMaxPasses * 256 * 8;
+// A second copy of the digit counts, for mid-size sorts on the context's own block: they launch no memset.  The histogram
+// kernel adds into the copy rs_ctx::hist_copy names, which is zero when a sort starts, and clears what the memset would
+// have: the OTHER copy (for the next sort), the tickets and the descriptor rows of this one.  Every path that does launch
+// the memset clears both copies, uses copy 0 and leaves hist_copy = 1.
+constexpr size_t kCtrlHist1 = kCtrlHist + kMaxPasses * 256 * 8;
+constexpr size_t kCtrlBase = kCtrlHist1 + kMaxPasses * 256 * 8;
 constexpr size_t kCtrlTicket = kCtrlBase + kMaxPasses * 256 * 8;
 constexpr size_t kCtrlMidDesc = kCtrlTicket + kMaxPasses * rsk::kTicketWords * sizeof(unsigned);
 constexpr size_t kMidDescTiles = 256;
 constexpr size_t kCtrlBytes = kCtrlMidDesc + kMidDescTiles * 256 * 4;
+static_assert(kCtrlHist % 16 == 0 && kCtrlHist1 % 16 == 0 && kCtrlTicket % 16 == 0 && kCtrlMidDesc % 16 == 0, "cleared 16 bytes per store");
 // chain mode only (rsort_kernels.hpp, "XCD chains"), zeroed only by sorts that use it:
 constexpr size_t kCtrlChainHist = (kCtrlBytes + 255) & ~size_t(255);                       // u64 [8 chains][8 passes][256] from the histogram kernel
 constexpr size_t kCtrlNextCnt = kCtrlChainHist + rsk::kXcds * rsk::kChainHistStride * 8;   // u64 [8 passes][8 chains][256] from the sweeps
@@ -403,7 +410,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
 
   char* ctrl = ws ? ws->ctrl : static_cast<char*>(c->ctrl.p);
   void* const desc = mid ? static_cast<void*>(ctrl + kCtrlMidDesc) : ws ? ws->desc : c->desc.p;
-  auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);
+  // Mid-size sorts on the context's own control block launch neither the memset nor the scan kernel: the histogram
+  // kernel clears what they need (kCtrlHist1) and every sweep scans the 256 digit counts of its pass itself
+  // (SweepArgs::counts).  Two launches less in a chain of seven.
+  const bool in_tile_scan = mid && !chain;      // (chain mode at mid sizes happens only under RSORT_CHAIN_MIN_TILES, in tests)
+  const bool self_clearing = in_tile_scan && !ws;
+  const int hist_copy = self_clearing ? c->hist_copy : 0;
+  auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + (hist_copy ? kCtrlHist1 : kCtrlHist));
   auto* gbase = reinterpret_cast<unsigned long long*>(ctrl + kCtrlBase);
   auto* tickets = reinterpret_cast<unsigned*>(ctrl + kCtrlTicket);
   auto* error_flag = reinterpret_cast<unsigned*>(ctrl + kCtrlError);
@@ -477,7 +490,10 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   int ev = 0;
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
   // counts, bases and tickets; NOT the error word behind them: it keeps a fault until check_kernel_error has read it
-  RS_HIP(c, hipMemsetAsync(ctrl + kCtrlHist, 0, kCtrlMidDesc - kCtrlHist + (mid ? tiles * 256 * 4 : 0), s));
+  if (!self_clearing) {
+    RS_HIP(c, hipMemsetAsync(ctrl + kCtrlHist, 0, kCtrlMidDesc - kCtrlHist + (mid ? tiles * 256 * 4 : 0), s));
+    if (!ws) c->hist_copy = 1;
+  }
   if (chain) RS_HIP(c, hipMemsetAsync(ctrl + kCtrlChainHist, 0, kCtrlBytesChain - kCtrlChainHist, s));
   // Chain mode keeps 4-byte descriptors and offsets up to 2^32 keys: a descriptor holds a count inside ONE chain (at most an
   // eighth of the keys plus a tile, below 2^30), and output offsets below 2^32 fit the 4-byte tables.  The one-chain
@@ -495,9 +511,17 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
   h.chain_hist = chain ? chain_hist : nullptr;
   h.chain_keys = chain ? static_cast<uint64_t>(chain_tiles) * tile_keys(key_bytes, value_bytes, true) : 0;
+  if (self_clearing) {
+    h.zero[0] = ctrl + (hist_copy ? kCtrlHist : kCtrlHist1);
+    h.zero_vecs[0] = static_cast<unsigned>(kMaxPasses * 256 * 8 / 16);
+    h.zero[1] = ctrl + kCtrlTicket;
+    h.zero_vecs[1] = static_cast<unsigned>((kCtrlMidDesc - kCtrlTicket + tiles * 256 * 4) / 16);
+  }
   launch_hist(h, key_bytes, chain ? 256u * hist_wgs_per_cu(key_bytes) : hist_grid(n, key_bytes), s);
-  hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase,
-                     static_cast<const unsigned long long*>(chain ? chain_hist : nullptr));
+  if (self_clearing) c->hist_copy ^= 1;
+  if (!in_tile_scan)
+    hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase,
+                       static_cast<const unsigned long long*>(chain ? chain_hist : nullptr));
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
 
   // Pass skipping (the device-side counterpart of getMaxLength, radix_sort.hpp:307-370, which lets the reference
@@ -551,6 +575,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     rsk::SweepArgs a{};
     a.keys_in = kin; a.keys_out = kout; a.vals_in = vin; a.vals_out = vout;
     a.desc = desc; a.ticket = tickets + p * rsk::kTicketWords; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
+    a.counts = in_tile_scan ? ghist + p * rsk::kRadix : nullptr;
     a.n = n;
     a.fmask_in = done == 0 ? fmask : 0; a.smask_in = done == 0 ? smask : 0;                    // first launched pass
     a.fmask_out = done == n_live - 1 ? fmask : 0; a.smask_out = done == n_live - 1 ? smask : 0;  // last launched pass
@@ -915,6 +940,7 @@ int rs_partition_device(rs_ctx* c, const void* d_keys_in, void* d_keys_out, cons
   const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
 
   RS_HIP(c, hipMemsetAsync(ctrl + kCtrlHist, 0, kCtrlMidDesc - kCtrlHist, s));       // (not the error word: see sort_device)
+  c->hist_copy = 1;                                                                   // (both copies cleared, copy 0 used: kCtrlHist1)
   RS_HIP(c, hipMemsetAsync(c->desc.p, 0, tiles * 256 * (wide ? 8 : 4), s));
   rsk::HistArgs h{};
   h.keys = d_keys_in; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
@@ -1042,7 +1068,8 @@ int rs_digit_histogram_device(rs_ctx* c, const void* d_keys, size_t n, int key_b
   hipStream_t s = c->stream;
   char* ctrl = static_cast<char*>(c->ctrl.p);
   auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlHist);
-  RS_HIP(c, hipMemsetAsync(ghist, 0, sizeof(uint64_t) * 256 * kMaxPasses, s));
+  RS_HIP(c, hipMemsetAsync(ghist, 0, kCtrlBase - kCtrlHist, s));       // both copies of the counts; copy 0 is used (kCtrlHist1)
+  c->hist_copy = 1;
   const uint64_t sign = 1ull << (key_bytes * 8 - 1);
   const uint64_t all = key_bytes == 8 ? ~0ull : ((1ull << (key_bytes * 8)) - 1ull);
   rsk::HistArgs h{};

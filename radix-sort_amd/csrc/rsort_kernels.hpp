@@ -203,6 +203,11 @@ struct HistArgs {
   // chain_keys == 0: one range, counts go to ghist.  Needs 16-byte aligned keys and chain_keys % (16 / sizeof(K)) == 0.
   unsigned long long* chain_hist;
   uint64_t chain_keys;
+  // Mid-size sorts (rsort_api.hip, sort_device): the kernel also clears up to two regions of the control block, 16 bytes
+  // per store, spread over the grid -- what a memset launched before it would have cleared (nothing in this kernel reads them;
+  // the sweeps that do come after it on the stream).  zero_vecs counts 16-byte units; 0 = nothing to clear.
+  void* zero[2];
+  unsigned zero_vecs[2];
 };
 constexpr unsigned kChainHistStride = 8 * 256;   // words between two chains' tables in chain_hist
 
@@ -241,6 +246,11 @@ __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
   constexpr int VEC = 16 / sizeof(K);            // 16 bytes per lane per load
   constexpr int UNROLL = 4;                      // loads in flight per lane
   __shared__ unsigned lh[MAX_PASSES * kRadix * kHistCols];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    uint4* z = static_cast<uint4*>(a.zero[r]);
+    for (unsigned i = blockIdx.x * BLOCK + threadIdx.x; i < a.zero_vecs[r]; i += gridDim.x * BLOCK) z[i] = uint4{0u, 0u, 0u, 0u};
+  }
   for (int i = threadIdx.x; i < MAX_PASSES * kRadix * kHistCols; i += BLOCK) lh[i] = 0;
   __syncthreads();
   unsigned* col = lh + (threadIdx.x & (kHistCols - 1));
@@ -406,7 +416,9 @@ struct SweepArgs {
   void* vals_out;
   void* desc;                       // [tiles][256] words of D
   unsigned* ticket;                 // kTicketWords counters for this pass (one per XCD), zero at launch
-  const unsigned long long* gbase;  // [256] for this pass
+  const unsigned long long* gbase;  // [256] for this pass: where each digit's run starts in the output
+  const unsigned long long* counts; // non-null (mid-size sorts, 4-byte descriptors, not chain mode): this pass' 256 digit counts;
+                                    // every tile scans them itself and gbase is not read -- one launch less per sort
   unsigned* error_flag;             // set non-zero on a look-back timeout
   uint64_t n;
   uint64_t fmask_in, smask_in;      // non-zero only for the first pass
@@ -633,6 +645,7 @@ struct SweepSmem {
   unsigned tile_start[kRadix];      // exclusive scan of the tile's digit counts
   D gofs[kRadix];                   // global offset of the digit's run minus tile_start
   unsigned wave_total[kRadix / kWave];
+  unsigned gwave_total[kRadix / kWave];   // the same for the scan of the whole array's digit counts (SweepArgs::counts)
   unsigned tile_id;
   unsigned out_of_range;            // some digit's run of this tile would end past the array (see the write-out)
 };
@@ -779,6 +792,14 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   const K* kin = static_cast<const K*>(a.keys_in) + tile_base;
   const K fmi = static_cast<K>(a.fmask_in), smi = static_cast<K>(a.smask_in);
   const bool xf_in = (a.fmask_in | a.smask_in) != 0;
+
+  // Mid-size sorts (SweepArgs::counts): a digit's thread fetches the whole array's count of its digit now and scans it
+  // next to the tile's own counts below (fewer than 2^30 keys: 32 bits hold it).
+  constexpr bool IN_TILE_BASE = !CHAIN && sizeof(D) == 4;
+  unsigned gcount = 0, gexcl = 0;
+  if constexpr (IN_TILE_BASE) {
+    if (a.counts != nullptr && tid < kRadix) gcount = static_cast<unsigned>(a.counts[tid]);
+  }
 
   // ---- load: wave-striped, so (item, lane) order == key order inside the wave's segment ----------
   K key[ITEMS];
@@ -963,12 +984,28 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     }
     inc = v;
     if (lane == kWave - 1) s.wave_total[wave] = v;
+    if constexpr (IN_TILE_BASE) {
+      if (a.counts != nullptr) {
+        unsigned g = gcount;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          unsigned u = __shfl_up(g, off, kWave);
+          if (lane >= static_cast<unsigned>(off)) g += u;
+        }
+        gexcl = g - gcount;
+        if (lane == kWave - 1) s.gwave_total[wave] = g;
+      }
+    }
 #if RS_PRIO_PRE_AGG
     __builtin_amdgcn_s_setprio(0);
 #endif
   }
   __syncthreads();
   if (tid < kRadix) {
+    if constexpr (IN_TILE_BASE) {
+      if (a.counts != nullptr)
+        for (unsigned w = 0; w < wave; ++w) gexcl += s.gwave_total[w];
+    }
     unsigned before = 0;
     for (unsigned w = 0; w < wave; ++w) before += s.wave_total[w];
     unsigned start = before + inc - my_count;
@@ -1060,7 +1097,9 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
       desc_store<CHAIN>(&desc[tile * kRadix + tid], word);
     }
     unsigned long long run_begin = excl;
-    if constexpr (CHAIN) run_begin += cs.cbase[tid]; else run_begin += a.gbase[tid];
+    if constexpr (CHAIN) run_begin += cs.cbase[tid];
+    else if (IN_TILE_BASE && a.counts != nullptr) run_begin += gexcl;
+    else run_begin += a.gbase[tid];
     s.gofs[tid] = static_cast<D>(run_begin - s.tile_start[tid]);
     // Offsets come from the up-front histogram; keys that change while the sort runs (a caller that did not wait for
     // whatever produces them) make the two disagree.  A tile with a run that would end past the array reports that

@@ -142,6 +142,60 @@ def test_histogram_of_key_aligned_subranges(engine, name):
             assert (np.asarray(h[p]).astype(np.int64) == want).all(), (name, lo, hi, p)
 
 
+def test_mid_size_sorts_between_other_calls(engine, oracle):
+    """Mid-size device sorts launch no memset: the histogram kernel clears the control block for them and for the sort
+    after them (two copies of the digit counts, used in turn).  One context, mid-size sorts interleaved with everything
+    else that writes the control block -- large sorts, pair sorts, the histogram and partition entry points, the
+    pre-check of the host-buffer calls -- every result against the oracle."""
+    import torch
+    rng = np.random.Generator(np.random.PCG64(23))
+    engine.set_precheck(False)
+
+    def mid(name, n, shape="randomized", seed=1):
+        dt, kb, xf = shapes.KEY_TYPES[name]
+        v = shapes.generate(name, n, shape, seed=seed)
+        t = torch.from_numpy(v.view(np.uint8).copy()).cuda()
+        engine.sort_keys_ptr(t.data_ptr(), n, kb, xf)
+        engine.synchronize()
+        assert t.cpu().numpy().tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), (name, n, shape)
+
+    try:
+        for k in range(3):
+            mid("u32", 100_003 + k, seed=k)                # copies 0, 1, 0 of the counts
+        mid("u64", 300_001)
+        mid("u16", 70_000)                                  # 2 passes: the other passes' rows of the counts stay clear
+        mid("f64", 250_000, "duplicates")
+        mid("u32", 5_000_000)                               # not mid-size: memset, scan kernel, pass skipping read-back
+        mid("u32", 4_000_000)                               # the largest mid-size sort (245 tiles)
+        mid("i32", 33_333)
+        v = shapes.generate("u32", 200_000, "randomized", seed=9)
+        t = torch.from_numpy(v.view(np.uint8).copy()).cuda()
+        h = engine.digit_histogram_ptr(t.data_ptr(), 200_000, 4, 0, 0, 32)
+        assert (np.asarray(h[3]).astype(np.int64) == np.bincount((v >> 24).astype(np.int64), minlength=256)).all()
+        mid("u32", 150_000, seed=4)
+        mid("i64", 150_000, seed=5)
+        out = torch.empty_like(t)
+        engine.partition_ptr(t.data_ptr(), out.data_ptr(), 200_000, 4, 0, 24, 32)
+        engine.synchronize()
+        got = out.cpu().numpy().view(np.uint32)
+        assert (got == v[np.argsort(v >> 24, kind="stable")]).all()
+        mid("u32", 150_000, seed=6)
+        mid("f32", 1_000_000, "nearly_sorted")
+        # host-buffer calls: pre-check read-back before the histogram, pairs through the same control block
+        engine.set_precheck(True)
+        a = shapes.generate("u32", 120_000, "sorted", seed=1)
+        assert engine.sort_keys_host(a, 0).tobytes() == a.tobytes()
+        b = shapes.generate("u64", 120_000, "randomized", seed=2)
+        wk, wp = oracle.sort_pairs(b, 0, mt=True)
+        gk, gp = engine.sort_pairs_host(b, transform=0)
+        assert gk.tobytes() == wk.tobytes() and np.array_equal(gp, wp)
+        engine.set_precheck(False)
+        mid("u32", 100_000, seed=7)
+        mid("u64", 2_000_000, seed=8)
+    finally:
+        engine.set_precheck(True)
+
+
 def test_small_inputs_down_the_general_path(oracle):
     """Inputs of at most one tile normally take rsk::small_sort_kernel (one workgroup, everything in LDS); with
     RSORT_SMALL=0 they go down the general path (histogram, tickets, look-back) instead, which must agree too.

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +89,20 @@ int main(int argc, char** argv) {
     float ms[16]; int cnt = 0; f_get(c, ms, 16, &cnt);
     if (it >= 2) { float t = 0; for (int i = 0; i < cnt; ++i) t += ms[i]; tot.push_back(t); hist.push_back(ms[0]); for (int i = 1; i < cnt; ++i) pass.push_back(ms[i]); }
   }
+  if (getenv("RS_TUNE_WALL")) {   // host-clock latency of one device-resident sort (call + wait), profiling off: median and minimum
+    f_prof(c, 0);
+    std::vector<double> w;
+    for (int it = 0; it < 300; ++it) {
+      CK(hipMemcpy(work, src, n * kb, hipMemcpyDeviceToDevice));
+      CK(hipDeviceSynchronize());
+      auto t0 = std::chrono::steady_clock::now();
+      int rc = vb ? f_pairs(c, work, vals, alt, valt, n, kb, vb, 0, 0, kb * 8) : f_sort(c, work, alt, n, kb, 0, 0, kb * 8);
+      if (rc || f_sync(c)) { printf("sort failed: %s\n", f_err(c)); return 1; }
+      w.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    std::sort(w.begin(), w.end());
+    printf("wall us: median %.1f min %.1f   ", w[w.size() / 2], w.front());
+  }
   CK(hipMemset(bad, 0, 4));
   if (kb == 4) check<uint32_t><<<2048, 256>>>((uint32_t*)work, n, bad, sums + 1); else check<uint64_t><<<2048, 256>>>((uint64_t*)work, n, bad, sums + 1);
   unsigned hb; unsigned long long hs[2];
@@ -115,6 +130,18 @@ int main(int argc, char** argv) {
       for (size_t i = 8; i < cnt; ++i) d.push_back((double)(long long)(st[(k + 1) * 4096 + i] - st[k * 4096 + i]) * 0.01);
       std::sort(d.begin(), d.end());
       if (!d.empty()) printf("   %-22s median %.2f us  p10 %.2f  p90 %.2f\n", names[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+    }
+  }
+  if (f_st && getenv("RS_TUNE_STAMP_ALL")) {   // few tiles (mid-size sorts): every stamped tile of the last pass, phase by phase
+    std::vector<unsigned long long> st(16 * 4096);
+    f_st(st.data());
+    size_t tile_keys = getenv("RS_TUNE_TILE") ? atoi(getenv("RS_TUNE_TILE")) : ((kb <= 4 && vb <= 4) ? 16384 : 8192); size_t tiles = (n + tile_keys - 1) / tile_keys, cnt = std::min<size_t>((tiles + 63) / 64, 4096);
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < cnt; ++i) t0 = std::min(t0, st[i]);
+    for (size_t i = 0; i < cnt; ++i) {
+      printf("   tile %4zu begins %6.2f us:", i * 64, (st[i] - t0) * 0.01);
+      for (int k = 0; k < 7; ++k) printf(" %6.2f", (double)(long long)(st[(k + 1) * 4096 + i] - st[k * 4096 + i]) * 0.01);
+      printf("   trips %llu empty %llu walked %llu\n", st[8 * 4096 + i], st[9 * 4096 + i], st[10 * 4096 + i]);
     }
   }
   if (f_st && getenv("RS_TUNE_CHAINS")) {   // chain mode: when did each XCD's chain start and finish (stamped tiles only, last stamped pass)
