@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <optional>
 #include <random>
 #include <string>
 #include <vector>
@@ -57,6 +59,25 @@ int main(int argc, char** argv) {
     for (size_t i = 0; ok && i < n_str; i++) ok = v[i].data == w[i].data;
     std::printf("{string key; long long data} randomized N=%zu sort(v,&key,true) end-to-end: %.1f ms = %.4f Gkeys/s (std::stable_sort %.1f ms)  %s\n",
                 n_str, ms, n_str / ms / 1e6, ms_std, ok ? "OK" : "WRONG");
+    if (std::getenv("FRONTEND_PHASES")) {   // the same call taken apart: where do the milliseconds go?
+      namespace dev = radix_sort::internal::device;
+      for (int it = 0; it < 2; it++) {
+        v = src;
+        auto proj = &Composite::key;
+        const std::size_t threads = dev::hostThreads(v.size(), true);
+        double t_asc = timed([&] { (void)dev::isAscending(v, proj); });
+        std::optional<dev::PackedStrings> p;
+        double t_pack = timed([&] { p.emplace(dev::packStrings(v, proj, threads)); });
+        dev::Uninitialized<std::uint64_t> perm(v.size());
+        rs_ctx* ctx = dev::context();
+        rs_ctx_set_host_threads(ctx, static_cast<int>(threads));
+        double t_sort = timed([&] { dev::check(ctx, rs_sort_strings(ctx, p->blob.data(), p->offsets.data(), v.size(), perm.data(), 1)); });
+        double t_apply = timed([&] { dev::applyPermutation(v, perm.data(), threads); });
+        double t_free = timed([&] { p.reset(); });
+        std::printf("   phases (%zu host threads): order check %.1f  pack %.1f  rs_sort_strings %.1f  apply permutation %.1f  free %.1f ms\n",
+                    threads, t_asc, t_pack, t_sort, t_apply, t_free);
+      }
+    }
   }
   {
     std::vector<PodRow> src(n_str);
