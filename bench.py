@@ -218,12 +218,15 @@ def bench_strings(eng, m):
     eng.sort_strings_host(blob[: 1 << 16], offsets[:1001].copy())          # warm-up (context, kernels)
     times, dev_ms = [], []
     eng.set_profiling(True)
-    for _ in range(2):
+    host_threads = min(12, os.cpu_count() or 1)     # what radix_sort::sort(v, proj, true) asks for (hostThreads, include/radix_sort.hpp)
+    eng.set_host_threads(host_threads)
+    for _ in range(3):
         t0 = time.perf_counter()
         perm = eng.sort_strings_host(blob, offsets, stable=True)
         times.append(time.perf_counter() - t0)
         dev_ms.append(sum(eng.profile()))       # HIP events around the device part (between upload and download)
     eng.set_profiling(False)
+    eng.set_host_threads(1)
     ok_perm = bool((np.bincount(perm.astype(np.int64), minlength=m) == 1).all())
     idx = rng.integers(0, m - 1, size=200_000)
     ok_order = True
@@ -244,7 +247,7 @@ def bench_strings(eng, m):
     level0_bytes = 303
     dev = min(dev_ms) if dev_ms and min(dev_ms) > 0 else None
     return {"strings": m, "ms": sec * 1e3, "mstrings_s": m / sec / 1e6, "host_bytes_per_string": moved / m,
-            "includes": "H2D of blob+offsets, MSD sort, D2H of the permutation",
+            "includes": "H2D of blob+offsets, MSD sort, D2H of the permutation", "host_threads": host_threads,
             "device_ms": dev, "device_mstrings_s": m / dev / 1e3 if dev else None,
             "device_bytes_per_string_level0": level0_bytes,
             "device_hbm_frac_level0": m * level0_bytes / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS if dev else None,
