@@ -413,8 +413,12 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // Mid-size sorts on the context's own control block launch neither the memset nor the scan kernel: the histogram
   // kernel clears what they need (kCtrlHist1) and every sweep scans the 256 digit counts of its pass itself
   // (SweepArgs::counts).  Two launches less in a chain of seven.
+  // Not while the stream is being captured into a graph: which copy of the counts is zero is host state, fixed at capture
+  // time, and every replay would add into the same copy.  A captured sort keeps its memset (and clears both copies).
   const bool in_tile_scan = mid && !chain;      // (chain mode at mid sizes happens only under RSORT_CHAIN_MIN_TILES, in tests)
-  const bool self_clearing = in_tile_scan && !ws;
+  hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+  if (in_tile_scan && !ws && hipStreamIsCapturing(s, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusActive; }
+  const bool self_clearing = in_tile_scan && !ws && capture == hipStreamCaptureStatusNone;
   const int hist_copy = self_clearing ? c->hist_copy : 0;
   auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + (hist_copy ? kCtrlHist1 : kCtrlHist));
   auto* gbase = reinterpret_cast<unsigned long long*>(ctrl + kCtrlBase);

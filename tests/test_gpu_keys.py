@@ -196,6 +196,45 @@ def test_mid_size_sorts_between_other_calls(engine, oracle):
         engine.set_precheck(True)
 
 
+def test_mid_size_sort_replayed_from_a_graph(oracle):
+    """A mid-size device sort queues its kernels and returns, so it can be captured into a HIP graph once its buffers
+    exist.  Replays must not depend on host state of the capture (which copy of the digit counts was clear then): three
+    replays over different keys, then an ordinary sort on the same context, all against the oracle."""
+    import torch
+    import radix_sort_amd as rs
+    n = 300_000
+    eng = rs.Engine(0)
+    try:
+        eng.set_precheck(False)
+        side = torch.cuda.Stream()
+        buf = torch.empty(n, dtype=torch.int32, device="cuda")
+        alt = torch.empty_like(buf)
+        eng.set_stream(side.cuda_stream)
+        with torch.cuda.stream(side):
+            buf.random_(0, 1 << 30)
+        side.synchronize()
+        eng.sort_keys_ptr(buf.data_ptr(), n, 4, 0, d_alt=alt.data_ptr())      # allocates the control block, loads the kernels
+        eng.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            eng.sort_keys_ptr(buf.data_ptr(), n, 4, 0, d_alt=alt.data_ptr())
+        for seed in (1, 2, 3):
+            v = shapes.generate("u32", n, "randomized", seed=seed)
+            buf.copy_(torch.from_numpy(v.view(np.int32)))
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert buf.cpu().numpy().view(np.uint32).tobytes() == oracle.sort_keys(v, 0, mt=True).tobytes(), seed
+        v = shapes.generate("u32", n, "duplicates", seed=4)
+        buf.copy_(torch.from_numpy(v.view(np.int32)))
+        torch.cuda.synchronize()
+        eng.sort_keys_ptr(buf.data_ptr(), n, 4, 0, d_alt=alt.data_ptr())
+        eng.synchronize()
+        assert buf.cpu().numpy().view(np.uint32).tobytes() == oracle.sort_keys(v, 0, mt=True).tobytes()
+    finally:
+        eng.close()
+
+
 def test_small_inputs_down_the_general_path(oracle):
     """Inputs of at most one tile normally take rsk::small_sort_kernel (one workgroup, everything in LDS); with
     RSORT_SMALL=0 they go down the general path (histogram, tickets, look-back) instead, which must agree too.
