@@ -110,8 +110,9 @@ int rs_sort_keys_device(rs_ctx* ctx, void* d_keys, void* d_alt, size_t n, int ke
  *   larger n is rejected with RS_ERR_ARG.  Histograms, tickets and look-back descriptors live in a static device array of
  *   4.5 MiB that every GPU the library runs on holds until the process ends.  All calls on one GPU share that array:
  *   calls that overlap on one GPU (two streams, two contexts, two threads) race and must be serialised by the caller;
- *   each call clears what it needs at its start.  A fault is reported by the next rs_ctx_synchronize, as for the other
- *   device entry points. */
+ *   each call clears what it needs at its start (on a stream that is being captured into a graph: with a kernel of the
+ *   library rather than memset nodes, which did not reliably clear again on replay).  A fault is reported by the next
+ *   rs_ctx_synchronize, as for the other device entry points. */
 #define RS_NOALLOC_MAX_KEYS ((size_t)1 << 25)
 int rs_sort_keys_device_noalloc(rs_ctx* ctx, void* d_keys, void* d_alt, size_t n, int key_bytes,
                                 int transform, int begin_bit, int end_bit);

@@ -189,6 +189,22 @@ int ensure(rs_ctx* c, DevBuf& b, size_t bytes) {
   return RS_OK;
 }
 
+// Zero `bytes` at p on the stream.  by_kernel: with a kernel of this library instead of hipMemsetAsync -- for sorts that are
+// being captured into a HIP graph.  Measured (ROCm 7.0, tools/dbg_graph2.py): a captured sort with memset nodes replayed
+// correctly as long as only copies ran between the replays; once other kernels had run on the device in between, the
+// memset nodes no longer cleared the tickets and every later replay moved nothing.  Kernel nodes replay as captured.
+int clear_async(rs_ctx* c, void* p, size_t bytes, hipStream_t s, bool by_kernel) {
+  if (bytes == 0) return RS_OK;
+  if (by_kernel && (bytes & 15u) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0 && (bytes >> 4) <= 0xFFFFFFFFull) {
+    const unsigned vecs = static_cast<unsigned>(bytes >> 4);
+    const unsigned grid = std::min<unsigned>((vecs + 255u) / 256u, 2048u);
+    hipLaunchKernelGGL(rsk::zero_kernel, dim3(grid), dim3(256), 0, s, static_cast<uint4*>(p), vecs);
+    return RS_OK;
+  }
+  RS_HIP(c, hipMemsetAsync(p, 0, bytes, s));
+  return RS_OK;
+}
+
 size_t tile_keys(int key_bytes, int value_bytes, bool chain = false) {
   return static_cast<size_t>(sweep_block(key_bytes, value_bytes, chain)) * sweep_items(key_bytes, value_bytes, chain);
 }
@@ -413,12 +429,14 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // Mid-size sorts on the context's own control block launch neither the memset nor the scan kernel: the histogram
   // kernel clears what they need (kCtrlHist1) and every sweep scans the 256 digit counts of its pass itself
   // (SweepArgs::counts).  Two launches less in a chain of seven.
-  // Not while the stream is being captured into a graph: which copy of the counts is zero is host state, fixed at capture
-  // time, and every replay would add into the same copy.  A captured sort keeps its memset (and clears both copies).
+  // Not while the stream is being captured into a graph: which copy of the counts is zero is host state, and a replay runs
+  // when the host is not looking.  A captured sort keeps its memset (both copies) and clears the counts again when it is
+  // done, so that whichever copy the next ordinary sort takes for clear is clear, however replays and calls interleave.
   const bool in_tile_scan = mid && !chain;      // (chain mode at mid sizes happens only under RSORT_CHAIN_MIN_TILES, in tests)
   hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
-  if (in_tile_scan && !ws && hipStreamIsCapturing(s, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusActive; }
-  const bool self_clearing = in_tile_scan && !ws && capture == hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+  const bool capturing = capture != hipStreamCaptureStatusNone;     // (only sorts that never wait for the device can be: mid-size ones and the workspace form)
+  const bool self_clearing = in_tile_scan && !ws && !capturing;
   const int hist_copy = self_clearing ? c->hist_copy : 0;
   auto* ghist = reinterpret_cast<unsigned long long*>(ctrl + (hist_copy ? kCtrlHist1 : kCtrlHist));
   auto* gbase = reinterpret_cast<unsigned long long*>(ctrl + kCtrlBase);
@@ -495,8 +513,8 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
   // counts, bases and tickets; NOT the error word behind them: it keeps a fault until check_kernel_error has read it
   if (!self_clearing) {
-    RS_HIP(c, hipMemsetAsync(ctrl + kCtrlHist, 0, kCtrlMidDesc - kCtrlHist + (mid ? tiles * 256 * 4 : 0), s));
-    if (!ws) c->hist_copy = 1;
+    if ((rc = clear_async(c, ctrl + kCtrlHist, kCtrlMidDesc - kCtrlHist + (mid ? tiles * 256 * 4 : 0), s, capturing)) != RS_OK) return rc;
+    if (!ws && !capturing) c->hist_copy = 1;
   }
   if (chain) RS_HIP(c, hipMemsetAsync(ctrl + kCtrlChainHist, 0, kCtrlBytesChain - kCtrlChainHist, s));
   // Chain mode keeps 4-byte descriptors and offsets up to 2^32 keys: a descriptor holds a count inside ONE chain (at most an
@@ -506,7 +524,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // (the rows this sort uses, not the whole reservation; should the few-valued rule below send a chain-mode sort of more
   // than 2^30 keys down the one-chain kernels, their 8-byte rows of 16384-key tiles take exactly the bytes of the 4-byte rows
   // of 8192-key tiles cleared here)
-  if (!mid) RS_HIP(c, hipMemsetAsync(desc, 0, tiles * 256 * ((chain ? wide_chain : wide) ? 8 : 4), s));
+  if (!mid && (rc = clear_async(c, desc, tiles * 256 * ((chain ? wide_chain : wide) ? 8 : 4), s, capturing)) != RS_OK) return rc;
 
   auto* chain_hist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlChainHist);
   auto* next_cnt = reinterpret_cast<unsigned long long*>(ctrl + kCtrlNextCnt);
@@ -605,6 +623,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     std::swap(vin, vout);
   }
   RS_HIP(c, hipGetLastError());
+  if (capturing && !ws && (rc = clear_async(c, ctrl + kCtrlHist, kCtrlBase - kCtrlHist, s, true)) != RS_OK) return rc;   // (see self_clearing)
   if (n_live & 1) {   // result sits in the alternate buffers
     RS_HIP(c, hipMemcpyAsync(keys, alt_keys, n * key_bytes, hipMemcpyDeviceToDevice, s));
     if (value_bytes) RS_HIP(c, hipMemcpyAsync(vals, alt_vals, n * value_bytes, hipMemcpyDeviceToDevice, s));
@@ -631,6 +650,8 @@ int check_kernel_error(rs_ctx* c) {
   if (flag & 2u)
     return fail(c, RS_ERR_KERNEL, "an output offset fell outside the array: the keys changed while the sort was running "
                                   "(the stream that produces them was not waited for?); the result is not a sort of the input");
+  if (flag & 4u)
+    return fail(c, RS_ERR_KERNEL, "a pass found its tile tickets already drawn (the control block was not clear when it started): nothing was moved");
   if (flag) return fail(c, RS_ERR_KERNEL, "onesweep look-back timed out (descriptor chain broken)");
   return RS_OK;
 }

@@ -304,6 +304,13 @@ __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
   }
 }
 
+// Clears `vecs` 16-byte units at p.  What hipMemsetAsync does, as a kernel of this library: sorts that are being captured
+// into a HIP graph use it, because memset NODES did not reliably run again when such a graph was replayed (rsort_api.hip,
+// clear_async).
+__global__ __launch_bounds__(256) void zero_kernel(uint4* p, unsigned vecs) {
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < vecs; i += gridDim.x * 256u) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. exclusive scan of each pass' digit counts (grid = passes, block = 256)
 // ------------------------------------------------------------------------------------------------
@@ -753,7 +760,12 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   for (int i = 0; i < static_cast<int>(sizeof(Cell)) * kRadix / 4 / kWave; ++i) reinterpret_cast<unsigned*>(s.whist[wave])[i * kWave + lane] = 0;
   __syncthreads();
 
-  if (s.tile_id == kNoTile) break;                // workgroup-uniform; without CHAIN it cannot happen (one workgroup per tile)
+  if (s.tile_id == kNoTile) {                     // workgroup-uniform
+    // Without CHAIN there is one workgroup per tile: a ticket beyond the last tile means the tickets were not clear when
+    // the pass started.  Reported (RS_ERR_KERNEL), not passed over: the pass would otherwise silently move nothing.
+    if (!CHAIN && tid == 0) __hip_atomic_fetch_or(a.error_flag, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    break;
+  }
   const uint64_t tile = s.tile_id;
   const uint64_t first_tile = CHAIN ? chain_first : 0u;   // the tile whose aggregate is its inclusive prefix
 #ifdef RS_STAMPS

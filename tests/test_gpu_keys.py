@@ -196,14 +196,22 @@ def test_mid_size_sorts_between_other_calls(engine, oracle):
         engine.set_precheck(True)
 
 
-def test_mid_size_sort_replayed_from_a_graph(oracle):
+@pytest.mark.parametrize("entry", ["rs_sort_keys_device", "rs_sort_keys_device_noalloc"])
+def test_mid_size_sort_replayed_from_a_graph(oracle, entry):
     """A mid-size device sort queues its kernels and returns, so it can be captured into a HIP graph once its buffers
-    exist.  Replays must not depend on host state of the capture (which copy of the digit counts was clear then): three
-    replays over different keys, then an ordinary sort on the same context, all against the oracle."""
+    exist; the entry point that allocates nothing is meant for exactly that.  Replays must neither depend on host state
+    of the capture (which copy of the digit counts was clear then) nor upset the ordinary sorts that run between them:
+    replays and calls interleaved, with other kernels running on the device in between (with only copies in between,
+    memset nodes of an earlier version replayed fine; with kernels they stopped clearing the tickets), every result
+    against the oracle."""
     import torch
     import radix_sort_amd as rs
     n = 300_000
     eng = rs.Engine(0)
+    if entry == "rs_sort_keys_device":
+        def sort(d_keys, d_alt): eng.sort_keys_ptr(d_keys, n, 4, 0, d_alt=d_alt)
+    else:
+        def sort(d_keys, d_alt): eng.sort_keys_noalloc_ptr(d_keys, d_alt, n, 4, 0)
     try:
         eng.set_precheck(False)
         side = torch.cuda.Stream()
@@ -213,24 +221,25 @@ def test_mid_size_sort_replayed_from_a_graph(oracle):
         with torch.cuda.stream(side):
             buf.random_(0, 1 << 30)
         side.synchronize()
-        eng.sort_keys_ptr(buf.data_ptr(), n, 4, 0, d_alt=alt.data_ptr())      # allocates the control block, loads the kernels
+        sort(buf.data_ptr(), alt.data_ptr())      # allocates the control block, loads the kernels
         eng.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
-            eng.sort_keys_ptr(buf.data_ptr(), n, 4, 0, d_alt=alt.data_ptr())
-        for seed in (1, 2, 3):
-            v = shapes.generate("u32", n, "randomized", seed=seed)
+            sort(buf.data_ptr(), alt.data_ptr())
+        # replays and ordinary calls in every order: r r r c r c c r r c
+        for step, how in enumerate("rrrcrccrrc"):
+            v = shapes.generate("u32", n, "duplicates" if step % 4 == 3 else "randomized", seed=step)
             buf.copy_(torch.from_numpy(v.view(np.int32)))
             torch.cuda.synchronize()
-            graph.replay()
-            torch.cuda.synchronize()
-            assert buf.cpu().numpy().view(np.uint32).tobytes() == oracle.sort_keys(v, 0, mt=True).tobytes(), seed
-        v = shapes.generate("u32", n, "duplicates", seed=4)
-        buf.copy_(torch.from_numpy(v.view(np.int32)))
-        torch.cuda.synchronize()
-        eng.sort_keys_ptr(buf.data_ptr(), n, 4, 0, d_alt=alt.data_ptr())
-        eng.synchronize()
-        assert buf.cpu().numpy().view(np.uint32).tobytes() == oracle.sort_keys(v, 0, mt=True).tobytes()
+            if how == "r":
+                graph.replay()                      # (runs on torch's current stream)
+                torch.cuda.synchronize()
+            else:
+                sort(buf.data_ptr(), alt.data_ptr())
+                eng.synchronize()
+            busy = torch.sort(buf.to(torch.int64)).values.sum().item()      # other kernels on the device between the steps
+            assert buf.cpu().numpy().view(np.uint32).tobytes() == oracle.sort_keys(v, 0, mt=True).tobytes(), (step, how, busy)
+        eng.synchronize()                           # no fault left behind by a replay
     finally:
         eng.close()
 
