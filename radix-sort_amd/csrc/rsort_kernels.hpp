@@ -227,8 +227,13 @@ constexpr int kHistCols = RS_HIST_COLS;
 // every shift is a compile-time constant (one v_bfe_u32 with immediates per digit).
 template <typename K, int MAX_PASSES, bool WHOLE>
 __device__ __forceinline__ void hist_add_key(K k, unsigned* col, const HistArgs& a) {
+#ifdef RS_HIST_TIMING_ONE_DIGIT    // timing experiment only (wrong results): what would a histogram of the first digit alone cost?
+  constexpr int COUNTED = 1;
+#else
+  constexpr int COUNTED = MAX_PASSES;
+#endif
 #pragma unroll
-  for (int p = 0; p < MAX_PASSES; ++p) {
+  for (int p = 0; p < COUNTED; ++p) {
     if constexpr (WHOLE) {
       unsigned w = sizeof(K) == 8 && p >= 4 ? static_cast<unsigned>(static_cast<uint64_t>(k) >> 32) : static_cast<unsigned>(k);
       atomicAdd(col + (p * kRadix + ((w >> ((p & 3) * 8)) & 0xFFu)) * kHistCols, 1u);
@@ -244,7 +249,10 @@ template <typename K, int BLOCK, bool WHOLE>
 __global__ __launch_bounds__(BLOCK) void digit_histogram_kernel(HistArgs a) {
   constexpr int MAX_PASSES = sizeof(K);
   constexpr int VEC = 16 / sizeof(K);            // 16 bytes per lane per load
-  constexpr int UNROLL = 4;                      // loads in flight per lane
+#ifndef RS_HIST_UNROLL
+#define RS_HIST_UNROLL 4
+#endif
+  constexpr int UNROLL = RS_HIST_UNROLL;         // loads in flight per lane
   __shared__ unsigned lh[MAX_PASSES * kRadix * kHistCols];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
