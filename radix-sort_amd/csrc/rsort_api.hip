@@ -370,7 +370,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // large enough to keep every XCD busy with its own chain, on devices where the XCC-id probe found all eight XCDs, with
   // the returning-add ranking, 4- and 8-byte keys, 16-byte aligned buffers (the histogram kernel counts per chain in
   // 16-byte packs; the sweeps fetch their keys by 16-byte LDS-DMA).
-  static const long chain_min_tiles = [] { const char* e = std::getenv("RSORT_CHAIN_MIN_TILES"); return e ? std::atol(e) : 4096l; }();
+  // From how many tiles on: measured per key width (tools/ab_tmp.sh sweep, profiles/r02_g_chain_threshold.txt, randomized and
+  // ordered shapes).  8-byte keys gain from about 1200 tiles (12 M keys: 0.479 against 0.505 ms; 33 M: 1.16 against 1.25 ms)
+  // and are level at 1024; 4-byte keys lose below about 12000 tiles (33 M keys: 0.388 against 0.352 ms with the one-chain
+  // kernels, 67 M: 0.69 against 0.67) and are level from 10^8 keys on; 8-byte keys with a 4-byte payload are level
+  // everywhere below 8192 tiles.  RSORT_CHAIN_MIN_TILES overrides all three (tests, A/B timing).
+  static const long chain_min_env = [] { const char* e = std::getenv("RSORT_CHAIN_MIN_TILES"); return e ? std::atol(e) : -1l; }();
+  const long chain_min_tiles = chain_min_env >= 0 ? chain_min_env : value_bytes ? 4096l : key_bytes == 8 ? 1024l : 12288l;
   static const bool chain_env = [] { const char* e = std::getenv("RSORT_CHAIN"); return !(e && e[0] == '0'); }();
   // Pairs: measured at N = 2^30 / 2^29, only 8-byte keys with a 4-byte payload gain (5.07 against 6.00 ms per pass; the
   // other three pair kernels run out of registers in the persistent form and lose), so only those use it.
