@@ -133,18 +133,29 @@ namespace radix_sort
 				return true;
 			}
 
-			// Host threads for the steps that stay on the CPU (key column, string packing, moving the objects): the
-			// reference's thresholds (getNumOfThreads :112-123) -- one thread below 2,000,000 elements, above that as many
-			// as the hardware has, at most 12 -- and only when the caller asked for multi-threading, as sortByIndices does
-			// (:1121-1153).  Not the reference's "largest power of two <= n / 1,000,000" in between: its threads each own
-			// a power-of-two share of the buckets, these only cut [0, n) into ranges, and what they do waits on memory
-			// (10^7 {string; long long} objects: 82 ms end to end with 8 threads, 61 ms with 12).
-			inline std::size_t hostThreads(std::size_t n, bool enableMultiThreading)
+			// Host threads.  Two users: the library's transfer lanes (rs_ctx_set_host_threads) and the steps that stay on the
+			// CPU here (key column, string packing, moving the objects).  Both only when the caller asked for multi-threading,
+			// as sortByIndices does (:1121-1153), and both capped like the reference's getNumOfThreads (:112-123): at most 12,
+			// at most what the hardware has.  Not the reference's "largest power of two <= n / 1,000,000" below the cap: its
+			// threads each own a power-of-two share of the buckets, these only cut [0, n) into ranges, and what they do waits on
+			// memory (10^7 {string; long long} objects: 82 ms end to end with 8 threads, 61 ms with 12).
+			//   transfers: from the reference's 2,000,000 elements on (10^6 unsigned: 0.56 ms with one lane, more with several);
+			//   packing / gathering strings and objects: from 250,000 on -- starting a dozen threads costs well under a
+			//   millisecond, one thread needs 13-20 ms for 10^6 strings or objects (STRING 10^6: 19.5 -> 7.8 ms).
+			inline std::size_t hostThreadsFrom(std::size_t n, bool enableMultiThreading, std::size_t threshold)
 			{
-				if (!enableMultiThreading || n < 2'000'000)
+				if (!enableMultiThreading || n < threshold)
 					return 1;
 				const std::size_t hw = std::max<std::size_t>(1, std::thread::hardware_concurrency());
 				return std::min(hw, std::size_t(12));
+			}
+			inline std::size_t hostThreads(std::size_t n, bool enableMultiThreading)       // transfer lanes
+			{
+				return hostThreadsFrom(n, enableMultiThreading, 2'000'000);
+			}
+			inline std::size_t helperThreads(std::size_t n, bool enableMultiThreading)     // packing, gathering
+			{
+				return hostThreadsFrom(n, enableMultiThreading, 250'000);
 			}
 
 			// body(lo, hi) over [0, n) cut into `threads` contiguous ranges (the last one takes the remainder)
@@ -281,11 +292,11 @@ namespace radix_sort
 			template <typename T, typename Proj>
 			inline void sortByStringKey(std::vector<T>& v, Proj& proj, bool stable, bool enableMultiThreading)
 			{
-				const std::size_t threads = hostThreads(v.size(), enableMultiThreading);
+				const std::size_t threads = helperThreads(v.size(), enableMultiThreading);
 				PackedStrings p = packStrings(v, proj, threads);
 				Uninitialized<std::uint64_t> perm(v.size());
 				rs_ctx* ctx = context();
-				check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(threads)));
+				check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(hostThreads(v.size(), enableMultiThreading))));
 				check(ctx, rs_sort_strings(ctx, p.blob.data(), p.offsets.data(), v.size(), perm.data(), stable ? 1 : 0));
 				applyPermutation(v, perm.data(), threads);
 			}
@@ -354,7 +365,7 @@ namespace radix_sort
 				{
 					device::checkKeyType<Key>();
 
-					const std::size_t threads = device::hostThreads(SIZE, enableMultiThreading);
+					const std::size_t threads = device::helperThreads(SIZE, enableMultiThreading);
 					// the key column (:1581-1585); a bool key is stored as a byte (std::vector<bool> has no element storage)
 					using Stored = std::conditional_t<std::same_as<Key, bool>, std::uint8_t, Key>;
 					device::Uninitialized<Stored> k(SIZE);
@@ -364,7 +375,7 @@ namespace radix_sort
 					});
 
 					rs_ctx* ctx = device::context();
-					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(threads)));
+					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(device::hostThreads(SIZE, enableMultiThreading))));
 					constexpr int XF = device::transformOf<Key>();
 					constexpr int BITS = static_cast<int>(sizeof(Key)) * 8;
 

@@ -64,13 +64,13 @@ int main(int argc, char** argv) {
       for (int it = 0; it < 2; it++) {
         v = src;
         auto proj = &Composite::key;
-        const std::size_t threads = dev::hostThreads(v.size(), true);
+        const std::size_t threads = dev::helperThreads(v.size(), true);
         double t_asc = timed([&] { (void)dev::isAscending(v, proj); });
         std::optional<dev::PackedStrings> p;
         double t_pack = timed([&] { p.emplace(dev::packStrings(v, proj, threads)); });
         dev::Uninitialized<std::uint64_t> perm(v.size());
         rs_ctx* ctx = dev::context();
-        rs_ctx_set_host_threads(ctx, static_cast<int>(threads));
+        rs_ctx_set_host_threads(ctx, static_cast<int>(dev::hostThreads(v.size(), true)));
         double t_sort = timed([&] { dev::check(ctx, rs_sort_strings(ctx, p->blob.data(), p->offsets.data(), v.size(), perm.data(), 1)); });
         double t_apply = timed([&] { dev::applyPermutation(v, perm.data(), threads); });
         double t_free = timed([&] { p.reset(); });
