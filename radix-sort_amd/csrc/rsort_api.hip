@@ -527,10 +527,15 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // eighth of the keys plus a tile, below 2^30), and output offsets below 2^32 fit the 4-byte tables.  The one-chain
   // kernels' descriptors hold counts over the whole array and need the 8-byte form from 2^30 keys on.
   const bool wide_chain = force_wide || n >= (size_t(1) << 32);
-  // (the rows this sort uses, not the whole reservation; should the few-valued rule below send a chain-mode sort of more
-  // than 2^30 keys down the one-chain kernels, their 8-byte rows of 16384-key tiles take exactly the bytes of the 4-byte rows
-  // of 8192-key tiles cleared here)
-  if (!mid && (rc = clear_async(c, desc, tiles * 256 * ((chain ? wide_chain : wide) ? 8 : 4), s, capturing)) != RS_OK) return rc;
+  // (the rows this sort uses, not the whole reservation.  Should the few-valued rule below send a chain-mode sort down the
+  // one-chain kernels, those use their own tile size and, beyond 2^30 keys, 8-byte rows: about the same bytes as the 4-byte
+  // rows of the 8192-key tiles, but rounded up separately -- ceil(n / 16384) * 8 can exceed ceil(n / 8192) * 4 by one row
+  // pair -- so the larger of the two is cleared.  The first version cleared the chain form's bytes only and refused the
+  // sort when they fell short: a multi-GPU rank that held a little more than 2^30 four-byte keys after the exchange, whose
+  // top digit takes few values by construction, hit exactly that.)
+  size_t desc_clear = tiles * 256 * ((chain ? wide_chain : wide) ? 8 : 4);
+  if (chain) desc_clear = std::max(desc_clear, tiles_for(n, key_bytes, value_bytes, false) * 256 * (wide ? size_t(8) : size_t(4)));
+  if (!mid && (rc = clear_async(c, desc, desc_clear, s, capturing)) != RS_OK) return rc;
 
   auto* chain_hist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlChainHist);
   auto* next_cnt = reinterpret_cast<unsigned long long*>(ctrl + kCtrlNextCnt);
@@ -559,7 +564,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // (under 10 us each below kAlwaysSweepTiles tiles).
   int live[kMaxPasses];     // the passes that are launched, in order
   int n_live = 0;
-  int min_bins = 256;       // fewest digit values in use over the launched passes (known only with the counts on the host)
+  int bins_of[kMaxPasses];  // digit values in use, per launched pass (known only with the counts on the host)
   if (ws || mid) {
     for (int p = 0; p < passes; ++p) live[n_live++] = p;
   } else {
@@ -570,33 +575,38 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       bool constant = false;
       for (int d = 0; d < 256; ++d)
         if (h_hist[p * 256 + d] == n) { constant = true; break; }
-      if (!constant) live[n_live++] = p;
       if (!constant) {
         int bins = 0;
         for (int d = 0; d < 256; ++d) bins += h_hist[p * 256 + d] != 0;
-        if (bins < min_bins) min_bins = bins;
+        bins_of[n_live] = bins;
+        live[n_live++] = p;
       }
     }
   }
   // Few-valued 4-byte keys (the 256-value "duplicates" shape: about 160 of 256 bins in use per pass) go down the
   // one-chain kernels: staged in digit order, their equal keys sit next to each other, and the chain kernels' counting adds
   // then cost more than the chained look-back saves (N = 2^30: 11.1 ms against 9.7 ms; 8-byte keys gain either way).
-  // The histogram and the zeroed descriptor rows serve both forms.
+  // The histogram and the zeroed descriptor rows serve both forms.  "Few-valued" = most of the launched passes see fewer
+  // than RS_FEW_VALUED_BINS digit values, not just one of them: a multi-GPU rank's keys share their top bits by construction
+  // (top digit: 256 / ranks values) and are otherwise as random as before the exchange.
   bool sweep_chain = chain;
   size_t sweep_tiles = tiles;
 #ifndef RS_FEW_VALUED_BINS
 #define RS_FEW_VALUED_BINS 200
 #endif
   static const int few_bins = [] { const char* e = std::getenv("RSORT_FEW_VALUED_BINS"); return e ? std::atoi(e) : RS_FEW_VALUED_BINS; }();   // (A/B timing)
-  if (chain && key_bytes == 4 && value_bytes <= 4 && min_bins < few_bins) {
+  int few_passes = 0;
+  if (!(ws || mid))
+    for (int i = 0; i < n_live; ++i) few_passes += bins_of[i] < few_bins;
+  if (chain && key_bytes == 4 && value_bytes <= 4 && 2 * few_passes > n_live) {
     sweep_chain = false;
     sweep_tiles = tiles_for(n, key_bytes, value_bytes, false);
   }
 
   void* kin = keys; void* kout = alt_keys;
   void* vin = vals; void* vout = alt_vals;
-  if (chain && !sweep_chain && wide && !wide_chain && sweep_tiles * 256 * 8 > tiles * 256 * 4)
-    return fail(c, RS_ERR_KERNEL, "descriptor rows of the one-chain fallback");      // (cannot happen: 16384- against 8192-key tiles)
+  if (chain && !sweep_chain && sweep_tiles * 256 * (wide ? size_t(8) : size_t(4)) > desc_clear)
+    return fail(c, RS_ERR_KERNEL, "descriptor rows of the one-chain fallback");      // (cannot happen: desc_clear covers both forms)
   const SweepLaunch launch{sweep_tiles, key_bytes, value_bytes, sweep_chain ? wide_chain : wide, c->rank_by_lds_atomic, sweep_chain, static_cast<unsigned>(c->cus), s};
   for (int done = 0; done < n_live; ++done) {
     const int p = live[done];

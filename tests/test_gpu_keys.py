@@ -411,15 +411,17 @@ def test_more_than_2_30_keys_on_the_device():
     key sum and the count of every value of the few-valued input (the size-independent properties of a sort)."""
     import torch
     import radix_sort_amd as rs
-    n = (1 << 30) + 12345
     eng = rs.Engine(0)
     eng.set_precheck(False)
     try:
-        for few in (False, True):
+        # (2^30 + 100 few-valued keys: the one-chain kernels' 8-byte descriptor rows, ceil(n / 16384) * 8 words per digit, are
+        # more than the chain form's ceil(n / 8192) * 4 -- a multi-GPU rank holding a little over 2^30 keys after its exchange
+        # was refused with "descriptor rows of the one-chain fallback" when only the latter were cleared)
+        for few, n in ((False, (1 << 30) + 12345), (True, (1 << 30) + 12345), (True, (1 << 30) + 100)):
             g = torch.Generator(device="cuda"); g.manual_seed(3)
             keys = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, device="cuda", generator=g)
             if few:
-                keys = (keys >> 24) * 65537                      # 256 values
+                keys = ((keys >> 25) & 127) * 0x01010101         # 128 values, and 128 digit values in every pass: the few-valued rule
             want_sum = int(keys.sum(dtype=torch.int64).item())
             want_hist = torch.bincount(((keys >> 24) + 128).to(torch.int64), minlength=256) if few else None
             torch.cuda.synchronize()
