@@ -78,6 +78,16 @@ int rs_ctx_set_precheck(rs_ctx* ctx, int enabled);
  * No counterpart in the reference (a CPU library). */
 int rs_ctx_set_tile_order(rs_ctx* ctx, int per_xcd);
 
+/* Hybrid form of the sort of whole 4-byte keys without payload (rs_sort_keys*, key_bytes 4, bits 0..32).  The reference's
+ * LSD loop (sortLsd radix_sort.hpp:506-526) moves every key once per digit; the hybrid form runs the two passes on the top
+ * digits only (count :125-153, prefix :193-208, scatter :447-470), after which the array is grouped by its top 16 bits,
+ * and finishes every group's low 16 bits inside LDS, one workgroup per group: 28 bytes of HBM traffic per key instead of 36.
+ * Same result, bit for bit (equal keys are identical, so no order among them exists to keep).
+ *   mode -1 (default): chosen per sort, from its size and its digit counts (groups must fit the LDS window);
+ *   mode  0: never;   mode 1: whenever the key shape allows it, at any size and distribution (tests).
+ * The environment variable RSORT_HYBRID gives the default of new contexts.  No counterpart in the reference. */
+int rs_ctx_set_hybrid(rs_ctx* ctx, int mode);
+
 /* Host threads the entry points that take HOST buffers (rs_sort_keys, rs_sort_pairs, rs_sort_strings) may use to move
  * the arrays to the GPU and back (default 1 = the calling thread only; at most 4 are used).  Arrays of 1 MiB and more
  * travel through pinned bounce buffers, one pipeline per thread; the front-end passes the reference's own thread rule

@@ -20,6 +20,7 @@ SYMBOLS = [
     ("rs_ctx_synchronize", _i, [_vp]),
     ("rs_ctx_set_precheck", _i, [_vp, _i]),
     ("rs_ctx_set_tile_order", _i, [_vp, _i]),
+    ("rs_ctx_set_hybrid", _i, [_vp, _i]),
     ("rs_ctx_set_host_threads", _i, [_vp, _i]),
     ("rs_ctx_set_profiling", _i, [_vp, _i]),
     ("rs_ctx_get_profile", _i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),

@@ -17,6 +17,7 @@
 
 #include "rsort_transfer.hpp"
 #include "rsort_kernels.hpp"
+#include "rsort_groups.hpp"
 #include "rsort_strings.hpp"
 
 // see Workspace below; named only in rs_ctx_create (hipGetSymbolAddress), everything else uses the address kept in the context
@@ -83,7 +84,16 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // where it pays -- sorts of at least this many tiles (16 M four-byte keys), which saturate the GPU on their own -- and
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
+constexpr size_t kHybridMinKeys = size_t(1) << 25;   // hybrid form of 4-byte key sorts from here on (below, its 65536 workgroups cost more than two sweeps)
 constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) neither pass skipping nor the order pre-check is worth a host synchronisation
+
+// Hybrid sort of 4-byte keys (rsort_groups.hpp): two sweeps on the top digits, then every group of equal top 16 bits is
+// finished in LDS by one workgroup.  Geometry of that kernel: 512 threads, up to 10 vectors of four keys each per thread.
+constexpr int kGroupBlock = 512;
+constexpr int kGroupMaxVec = 10;
+constexpr size_t kGroupCap = size_t(kGroupBlock) * kGroupMaxVec * 4 - 3;   // keys of the largest group the LDS window holds at any alignment
+constexpr unsigned kGroupCount = 65536;
+constexpr size_t kGroupsBytes = (size_t(kGroupCount) + 1 + kGroupCount + 1) * sizeof(unsigned);   // start table + list of oversize groups
 
 struct DevBuf {
   void* p = nullptr;
@@ -96,7 +106,7 @@ struct rs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
-  DevBuf alt_keys, alt_vals, desc, ctrl, strbuf;
+  DevBuf alt_keys, alt_vals, desc, ctrl, strbuf, groups;
   // ctrl layout: kCtrl* below
   bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
   bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create (and cleared by rs_ctx_set_tile_order)
@@ -110,6 +120,9 @@ struct rs_ctx {
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   bool last_unchanged = false;   // the last sort_device found its input already in order and moved nothing
+  int hybrid_mode = -1;          // hybrid form of 4-byte key sorts: -1 chosen per sort, 0 never, 1 whenever the shape allows (rs_ctx_set_hybrid; RSORT_HYBRID at creation)
+  unsigned group_max_vec = 0;    // test hook: groups of more vectors than this go to the big-group kernel (0 = what the LDS window holds)
+  bool last_hybrid = false;      // the last sort_device took the hybrid form
   hipEvent_t ev[kMaxPasses + 2] = {};
   int ev_count = 0;
   rst::Mover mover;        // host <-> HBM legs of the host-buffer entry points (rsort_transfer.hpp)
@@ -360,6 +373,7 @@ void launch_reverse_k(void* keys, size_t n, hipStream_t s) {
 int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_vals, size_t n, int key_bytes,
                 int value_bytes, int transform, int begin_bit, int end_bit, const Workspace* ws = nullptr) {
   c->last_unchanged = false;
+  c->last_hybrid = false;
   if (n < 2) { c->ev_count = 0; return RS_OK; }
   hipStream_t s = c->stream;
   const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
@@ -565,12 +579,14 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   int live[kMaxPasses];     // the passes that are launched, in order
   int n_live = 0;
   int bins_of[kMaxPasses];  // digit values in use, per launched pass (known only with the counts on the host)
+  unsigned long long h_hist_keep[kMaxPasses * 256];   // the counts themselves (hybrid form, below)
   if (ws || mid) {
     for (int p = 0; p < passes; ++p) live[n_live++] = p;
   } else {
     unsigned long long h_hist[kMaxPasses * 256];
     RS_HIP(c, hipMemcpyAsync(h_hist, ghist, sizeof(unsigned long long) * 256 * passes, hipMemcpyDeviceToHost, s));
     RS_HIP(c, hipStreamSynchronize(s));
+    std::memcpy(h_hist_keep, h_hist, sizeof(unsigned long long) * 256 * passes);
     for (int p = 0; p < passes; ++p) {
       bool constant = false;
       for (int d = 0; d < 256; ++d)
@@ -603,11 +619,40 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     sweep_tiles = tiles_for(n, key_bytes, value_bytes, false);
   }
 
+  // Hybrid form for whole 4-byte keys without payload (rsort_groups.hpp): only the two top digits are swept; the sweeps
+  // leave the array grouped by its top 16 bits, and each group's low 16 bits are sorted in LDS by one workgroup -- one read
+  // and one write of the keys instead of two of each.  Same result (keys only: equal keys are bit-identical).
+  // Chosen when the groups will (almost all) fit the LDS window: sizes where the mean group does, top digits whose
+  // counts say so (the product of the two largest digit shares bounds the largest group when the digits are independent;
+  // groups that turn out larger anyway are sorted by rsk::group_big_kernel, correct at any size, only slower), and low digits
+  // that are not few-valued (their LDS counters would queue; the four-pass form skips or peels such digits).
+  // rs_ctx_set_hybrid / RSORT_HYBRID: 0 never, 1 whenever the shape allows it (tests: any size, any distribution).
+  const int hybrid_env = c->hybrid_mode;
+  bool hybrid = false;
+  if (hybrid_env != 0 && !ws && !mid && !wide && value_bytes == 0 && key_bytes == 4 && begin_bit == 0 && end_bit == 32 &&
+      n_live == 4 && n < (size_t(1) << 32) && c->rank_by_lds_atomic && (reinterpret_cast<uintptr_t>(keys) & 3u) == 0) {
+    if (hybrid_env == 1) {
+      hybrid = true;
+    } else {
+      unsigned long long mx[4] = {0, 0, 0, 0};
+      for (int p = 0; p < 4; ++p)
+        for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
+      const double bound = static_cast<double>(mx[3]) * static_cast<double>(mx[2]) / static_cast<double>(n);   // largest group if the top digits are independent
+      hybrid = n >= kHybridMinKeys && bound <= 0.95 * kGroupCap && mx[0] <= n / 16 && mx[1] <= n / 16;
+    }
+  }
+  if (hybrid) {
+    c->last_hybrid = true;
+    if ((rc = ensure(c, c->groups, kGroupsBytes)) != RS_OK) return rc;
+    live[0] = 2; live[1] = 3; n_live = 2;
+  }
+
   void* kin = keys; void* kout = alt_keys;
   void* vin = vals; void* vout = alt_vals;
   if (chain && !sweep_chain && sweep_tiles * 256 * (wide ? size_t(8) : size_t(4)) > desc_clear)
     return fail(c, RS_ERR_KERNEL, "descriptor rows of the one-chain fallback");      // (cannot happen: desc_clear covers both forms)
   const SweepLaunch launch{sweep_tiles, key_bytes, value_bytes, sweep_chain ? wide_chain : wide, c->rank_by_lds_atomic, sweep_chain, static_cast<unsigned>(c->cus), s};
+  rsk::SweepArgs last_sweep{};
   for (int done = 0; done < n_live; ++done) {
     const int p = live[done];
     rsk::SweepArgs a{};
@@ -616,7 +661,8 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.counts = in_tile_scan ? ghist + p * rsk::kRadix : nullptr;
     a.n = n;
     a.fmask_in = done == 0 ? fmask : 0; a.smask_in = done == 0 ? smask : 0;                    // first launched pass
-    a.fmask_out = done == n_live - 1 ? fmask : 0; a.smask_out = done == n_live - 1 ? smask : 0;  // last launched pass
+    const bool stores_result = done == n_live - 1 && !hybrid;                                  // last launched pass (the hybrid form's group kernel stores the result)
+    a.fmask_out = stores_result ? fmask : 0; a.smask_out = stores_result ? smask : 0;
     a.shift = begin_bit + p * rsk::kRadixBits;
     a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
     a.per_xcd_order = c->per_xcd_order && sweep_tiles >= kPerXcdMinTiles ? 1 : 0;
@@ -637,6 +683,37 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     std::swap(kin, kout);
     std::swap(vin, vout);
+    last_sweep = a;
+  }
+  if (hybrid) {
+    // (two sweeps: the grouped keys are back in `keys`, the second sweep's input is intact in alt_keys)
+    auto* start = static_cast<unsigned*>(c->groups.p);
+    unsigned* big_list = start + kGroupCount + 1;
+    RS_HIP(c, hipMemsetAsync(big_list, 0, sizeof(unsigned), s));
+    rsk::TableArgs t{};
+    t.desc = static_cast<const uint32_t*>(desc);
+    t.keys_in = static_cast<const uint32_t*>(last_sweep.keys_in);
+    t.gbase_lo = gbase + 2 * rsk::kRadix; t.gbase_hi = gbase + 3 * rsk::kRadix;
+    t.chain_cnt = sweep_chain ? last_sweep.chain_cnt : nullptr;
+    t.chain_cnt_stride = last_sweep.chain_cnt_stride;
+    t.chain_tiles = sweep_chain ? chain_tiles : 0u;
+    t.tile = static_cast<unsigned>(tile_keys(key_bytes, value_bytes, sweep_chain));
+    t.n = static_cast<unsigned>(n);
+    t.shift_hi = 24;
+    t.start = start;
+    hipLaunchKernelGGL(rsk::group_table_kernel, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
+    rsk::GroupArgs ga{};
+    ga.keys = keys; ga.start = start; ga.groups = kGroupCount; ga.low_bits = 16;
+    ga.fmask_out = fmask; ga.smask_out = smask;
+    ga.big_list = big_list; ga.big_cap = kGroupCount;
+    ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, kGroupBlock * kGroupMaxVec) : kGroupBlock * kGroupMaxVec;
+    hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 2>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
+    if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+    rsk::BigArgs ba{};
+    ba.keys = keys; ba.alt = alt_keys; ba.start = start; ba.big_list = big_list; ba.big_cap = kGroupCount; ba.low_bits = 16;
+    ba.fmask_out = fmask; ba.smask_out = smask;
+    hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
+    if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
   }
   RS_HIP(c, hipGetLastError());
   if (capturing && !ws && (rc = clear_async(c, ctrl + kCtrlHist, kCtrlBase - kCtrlHist, s, true)) != RS_OK) return rc;   // (see self_clearing)
@@ -778,6 +855,7 @@ int rs_ctx_create(rs_ctx** out, int device) {
     return RS_ERR_HIP;
   }
   c->stream = c->own_stream;
+  if (const char* e = std::getenv("RSORT_HYBRID")) c->hybrid_mode = std::atoi(e) < 0 ? -1 : std::atoi(e) > 0 ? 1 : 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
@@ -847,7 +925,7 @@ int rs_ctx_destroy(rs_ctx* c) {
   if (!c) return RS_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->alt_keys, &c->alt_vals, &c->desc, &c->ctrl, &c->strbuf})
+  for (DevBuf* b : {&c->alt_keys, &c->alt_vals, &c->desc, &c->ctrl, &c->strbuf, &c->groups})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -888,6 +966,22 @@ int rs_ctx_set_precheck(rs_ctx* c, int enabled) {
   c->precheck = enabled != 0;
   return RS_OK;
 }
+
+int rs_ctx_set_hybrid(rs_ctx* c, int mode) {
+  if (!c) return RS_ERR_ARG;
+  if (mode < -1 || mode > 1) return fail(c, RS_ERR_ARG, "hybrid mode must be -1 (per sort), 0 (never) or 1 (whenever the shape allows)");
+  c->hybrid_mode = mode;
+  return RS_OK;
+}
+
+// Test hooks, not in rsort_hip.h: the largest group (in 16-byte vectors) the LDS kernel of the hybrid form takes (smaller
+// values push groups to the big-group kernel at test sizes), and whether the last device sort took the hybrid form.
+int rs_debug_set_group_limit(rs_ctx* c, unsigned max_vec) {
+  if (!c) return RS_ERR_ARG;
+  c->group_max_vec = max_vec;
+  return RS_OK;
+}
+int rs_debug_last_hybrid(const rs_ctx* c) { return c && c->last_hybrid ? 1 : 0; }
 
 int rs_ctx_set_tile_order(rs_ctx* c, int per_xcd) {
   if (!c) return RS_ERR_ARG;

@@ -1,0 +1,393 @@
+// rsort_groups.hpp -- the "finish in LDS" half of the hybrid sort of 4-byte keys (keys only).
+//
+// The LSD loop of the reference (sortLsd, radix_sort.hpp:506-526) moves every key once per digit: 4 reads + 4 writes for
+// 4-byte keys.  Here the two TOP digits are sorted first by two onesweep passes (bits 16-23, then 24-31: stable, so the
+// array is then grouped by its top 16 bits, 65536 groups of n / 65536 keys on uniform keys, each group in input order), and
+// the two LOW digits are sorted by ONE kernel in which a workgroup takes a whole group into LDS, sorts it there with two
+// 8-bit passes and writes it back in place: one read and one write of the keys instead of two of each (28 instead of the
+// canonical 36 bytes per key for the whole sort).  Same result: the array ends up ordered by (top 16 bits, low 16 bits).
+// Keys only: equal keys are bit-identical, so nothing here has to be stable with respect to the INPUT order, only the
+// second LDS pass with respect to the first.
+//
+//   group_table_kernel   where each of the 65536 groups starts, from what the second sweep left behind (its look-back
+//                        descriptors hold, per tile, the inclusive digit counts): no pass over the keys, no atomics
+//   group_sort_kernel    one workgroup per group: load (16 bytes per lane), LDS pass on bits 0-7 (order-free: shared
+//                        counters), LDS pass on bits 8-15 (stable: per-wave counters, as the sweep ranks), store (16 bytes
+//                        per lane).  Groups that do not fit the LDS window are left alone and put on a list
+//   group_big_kernel     the groups on that list, one workgroup each, by ranges of values through the alternate buffer
+#pragma once
+#include "rsort_kernels.hpp"
+
+namespace rsk {
+
+// -DRS_GROUP_ABL=bits: timing experiments only (results wrong): 1 no counting adds, 2 no cursor adds in the first scatter,
+// 4 no second pass, 8 no stores, 16 no loads
+#ifndef RS_GROUP_ABL
+#define RS_GROUP_ABL 0
+#endif
+
+struct GroupArgs {
+  void* keys;                  // grouped by the bits above low_bits; each group is sorted in place
+  const unsigned* start;       // [groups + 1] first element of each group; start[groups] = n
+  unsigned groups;
+  int low_bits;                // bits still to sort, 1..16 (values are staged as 16-bit words)
+  uint64_t fmask_out, smask_out;   // inverse key transform, applied in the store
+  unsigned* big_list;          // groups too large for the LDS window: [0] = how many, [1..] = group numbers
+  unsigned big_cap;            // room in big_list (entries)
+  unsigned max_vec;            // groups whose window has more 16-byte vectors than this are left to the big-group kernel (<= BLOCK * MAXV)
+};
+
+template <int BLOCK, int MAXV>
+struct GroupSmem {
+  static constexpr int WAVES = BLOCK / kWave;
+  static constexpr int CAP = BLOCK * MAXV * 4;          // elements of the largest window
+  alignas(16) unsigned short val[CAP + 8];   // (+8: pads of a window that starts up to 3 elements before its group land behind CAP)
+  alignas(16) unsigned hist[kRadix];         // pass 1: digit counts, then the cursors of the scatter
+  unsigned whist[WAVES][kRadix]; // pass 2: per-wave counters, then start + prefix over the waves
+  unsigned wave_total[kRadix / kWave];
+};
+
+// One group through LDS.  IT = 16-byte vectors per thread (compile time: the rounds of every phase are straight-line code).
+// The window is the 16-byte aligned range of the array that covers the group; window elements outside the group and the
+// elements of vectors beyond the window are "pads": they take the largest value, sort behind every real key and are never
+// stored.  Real key of final rank j lands at window element head + j, so the store phase writes whole aligned vectors.
+template <typename K, int BLOCK, int MAXV, int IT>
+__device__ __forceinline__ void group_sort_body(GroupSmem<BLOCK, MAXV>& s, K* win, unsigned head, unsigned len, unsigned nvec,
+                                                K top, int low_bits, K fmo, K smo) {
+  static_assert(sizeof(K) == 4, "4-byte keys");
+  constexpr int WAVES = BLOCK / kWave;
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const unsigned lowmask = (1u << low_bits) - 1u;
+  const bool two = low_bits > kRadixBits;
+
+  // ---- load: 16 bytes per lane, consecutive lanes consecutive vectors --------------------------------
+  const uint4* wv = reinterpret_cast<const uint4*>(win);
+  uint4 x[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const unsigned v = k * BLOCK + tid;
+    x[k] = uint4{~0u, ~0u, ~0u, ~0u};
+    if (!(RS_GROUP_ABL & 16) && v < nvec) x[k] = wv[v];
+    if (RS_GROUP_ABL & 16) x[k] = uint4{v * 2654435761u, v * 40503u, v ^ 0x5bd1e995u, v * 7u};
+  }
+  if (tid < kRadix) s.hist[tid] = 0;
+#pragma unroll
+  for (int i = 0; i < kRadix / kWave; ++i) s.whist[wave][i * kWave + lane] = 0;
+  __syncthreads();
+
+  // ---- pass 1, bits 0-7: count (any order will do) ---------------------------------------------------
+  unsigned lo[2 * IT];          // two 16-bit values per register
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const unsigned e = 4u * (k * BLOCK + tid) - head;       // rank of x[k].x inside the group if it belongs to it (wraps below head)
+    const unsigned a0 = e < len ? x[k].x & lowmask : lowmask;
+    const unsigned a1 = e + 1u < len ? x[k].y & lowmask : lowmask;
+    const unsigned a2 = e + 2u < len ? x[k].z & lowmask : lowmask;
+    const unsigned a3 = e + 3u < len ? x[k].w & lowmask : lowmask;
+    if (!(RS_GROUP_ABL & 1)) {
+      atomicAdd(&s.hist[a0 & 255u], 1u);
+      atomicAdd(&s.hist[a1 & 255u], 1u);
+      atomicAdd(&s.hist[a2 & 255u], 1u);
+      atomicAdd(&s.hist[a3 & 255u], 1u);
+    }
+    lo[2 * k] = a0 | (a1 << 16);
+    lo[2 * k + 1] = a2 | (a3 << 16);
+  }
+  __syncthreads();
+  // exclusive scan of the 256 counts by one wave, four digits per lane
+  if (wave == 0) {
+    const uint4 c = reinterpret_cast<const uint4*>(s.hist)[lane];
+    const unsigned sum = c.x + c.y + c.z + c.w;
+    unsigned inc = sum;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const unsigned u = __shfl_up(inc, off, kWave);
+      if (lane >= static_cast<unsigned>(off)) inc += u;
+    }
+    unsigned b = inc - sum + (two ? 0u : head);            // (a single pass scatters straight to the store layout)
+    uint4 o;
+    o.x = b; b += c.x; o.y = b; b += c.y; o.z = b; b += c.z; o.w = b;
+    reinterpret_cast<uint4*>(s.hist)[lane] = o;
+  }
+  __syncthreads();
+  // scatter: a returning add on the digit's cursor hands out the slots of its run (eight keys at a time: registers)
+  {
+    constexpr int SB = 2 * IT % 4 == 0 ? 4 : 2 * IT % 2 == 0 ? 2 : 1;   // registers of lo[] per batch
+#pragma unroll
+    for (int b = 0; b < 2 * IT; b += SB) {
+      unsigned pos[2 * SB];
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        if (RS_GROUP_ABL & 2) { pos[2 * k] = 4u * ((b + k) / 2 * BLOCK + tid) + 2 * ((b + k) & 1); pos[2 * k + 1] = pos[2 * k] + 1; continue; }
+        pos[2 * k] = atomicAdd(&s.hist[lo[b + k] & 255u], 1u);
+        pos[2 * k + 1] = atomicAdd(&s.hist[(lo[b + k] >> 16) & 255u], 1u);
+      }
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        s.val[pos[2 * k]] = static_cast<unsigned short>(lo[b + k]);
+        s.val[pos[2 * k + 1]] = static_cast<unsigned short>(lo[b + k] >> 16);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 2, bits 8-15: stable with respect to the order pass 1 left --------------------------------
+  if (two && !(RS_GROUP_ABL & 4)) {                           // workgroup-uniform
+    constexpr int R = 4 * IT;                                 // rounds of 64 per wave
+    const unsigned segbase = wave * (R * kWave) + lane;
+    unsigned kr[R];                                           // value | rank << 16
+#pragma unroll
+    for (int r = 0; r < R; ++r) kr[r] = s.val[segbase + r * kWave];
+#pragma unroll
+    for (int r = 0; r < R; ++r) kr[r] |= rank_add<true>(s.whist[wave], kr[r] >> 8) << 16;
+    __syncthreads();
+    unsigned my_count = 0, inc = 0;
+    if (tid < kRadix) {
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) my_count += s.whist[w][tid];
+      unsigned v = my_count;
+#pragma unroll
+      for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned u = __shfl_up(v, off, kWave);
+        if (lane >= static_cast<unsigned>(off)) v += u;
+      }
+      inc = v;
+      if (lane == kWave - 1) s.wave_total[wave] = v;
+    }
+    __syncthreads();
+    if (tid < kRadix) {
+      unsigned sum = head + inc - my_count;
+      for (unsigned w = 0; w < wave; ++w) sum += s.wave_total[w];
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        const unsigned c = s.whist[w][tid];
+        s.whist[w][tid] = sum;
+        sum += c;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < R; b += 4) {
+      unsigned pos[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pos[r] = s.whist[wave][(kr[b + r] >> 8) & 255u] + (kr[b + r] >> 16);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s.val[pos[r]] = static_cast<unsigned short>(kr[b + r]);
+    }
+    __syncthreads();
+  }
+
+  // ---- store: whole aligned vectors; the first and the last vector of the window element by element ----
+  const bool xf_out = (fmo | smo) != 0;
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const unsigned v = k * BLOCK + tid;
+    if (v < nvec && !(RS_GROUP_ABL & 8)) {
+      const uint2 p = reinterpret_cast<const uint2*>(s.val)[v];
+      K o0 = top | (p.x & 0xFFFFu), o1 = top | (p.x >> 16), o2 = top | (p.y & 0xFFFFu), o3 = top | (p.y >> 16);
+      if (xf_out) { o0 = xf_inverse(o0, fmo, smo); o1 = xf_inverse(o1, fmo, smo); o2 = xf_inverse(o2, fmo, smo); o3 = xf_inverse(o3, fmo, smo); }
+      const unsigned e = 4u * v - head;
+      if (4u * v >= head && e + 3u < len) {
+        reinterpret_cast<uint4*>(win)[v] = uint4{o0, o1, o2, o3};
+      } else {
+        if (e < len) win[4u * v] = o0;
+        if (e + 1u < len) win[4u * v + 1u] = o1;
+        if (e + 2u < len) win[4u * v + 2u] = o2;
+        if (e + 3u < len) win[4u * v + 3u] = o3;
+      }
+    }
+  }
+}
+
+template <typename K, int BLOCK, int MAXV, int MIN_BLOCKS>
+__global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group_sort_kernel(GroupArgs a) {
+  __shared__ GroupSmem<BLOCK, MAXV> s;
+  const unsigned g = blockIdx.x;
+  const unsigned start = a.start[g], end = a.start[g + 1];
+  if (end <= start + 1u) {                      // empty, or one key: in place already -- but the store applies the transform
+    if (end == start || !(a.fmask_out | a.smask_out)) return;
+  }
+  const unsigned len = end - start;
+  K* keys = static_cast<K*>(a.keys);
+  const unsigned head = static_cast<unsigned>((reinterpret_cast<uintptr_t>(keys + start) & 15u) / sizeof(K));
+  K* win = keys + start - head;
+  const unsigned nvec = (head + len + 3u) / 4u;
+  if (nvec > a.max_vec) {   // workgroup-uniform: does not fit, left to group_big_kernel
+    if (threadIdx.x == 0) {
+      const unsigned slot = atomicAdd(&a.big_list[0], 1u);
+      if (slot < a.big_cap) a.big_list[1 + slot] = g;
+    }
+    return;
+  }
+  const K top = static_cast<K>(g) << a.low_bits;
+  const K fmo = static_cast<K>(a.fmask_out), smo = static_cast<K>(a.smask_out);
+  const unsigned it = (nvec + BLOCK - 1) / BLOCK;
+  switch (it) {      // (one instantiation per vector count: a group of 16384 +- 130 keys takes 8 or 9 of 512 threads' vectors)
+#define RS_GROUP_CASE(N) case N: if constexpr (N <= MAXV) group_sort_body<K, BLOCK, MAXV, N>(s, win, head, len, nvec, top, a.low_bits, fmo, smo); break;
+    RS_GROUP_CASE(1) RS_GROUP_CASE(2) RS_GROUP_CASE(3) RS_GROUP_CASE(4) RS_GROUP_CASE(5) RS_GROUP_CASE(6)
+    RS_GROUP_CASE(7) RS_GROUP_CASE(8) RS_GROUP_CASE(9) RS_GROUP_CASE(10) RS_GROUP_CASE(11) RS_GROUP_CASE(12)
+#undef RS_GROUP_CASE
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Where the groups start
+// ------------------------------------------------------------------------------------------------
+// After the sweep on the upper top digit (hi) of an array that the sweep before it had ordered by the lower top digit (lo),
+// group (hi, lo) starts at
+//     gbase_hi[hi] + #{keys with upper digit hi among the sweep's input positions [0, gbase_lo[lo])},
+// because a stable pass hands out a digit's output slots in input order.  The count up to an input position is what the
+// sweep's look-back descriptors hold for whole tiles (every tile's word ends as the inclusive count of its digit over the
+// tiles of its chain up to itself), plus the counts of the chains before, plus a partial tile that is counted here from the
+// sweep's input, which is still intact in the other buffer.  One workgroup per value of the lower digit (the boundary it
+// looks at), one thread per value of the upper digit; at most one tile of keys is read per workgroup.
+struct TableArgs {
+  const uint32_t* desc;                  // [tiles][256] 4-byte descriptors left by the sweep on the upper digit
+  const uint32_t* keys_in;               // that sweep's input
+  const unsigned long long* gbase_lo;    // [256] where each value of the lower digit starts in keys_in
+  const unsigned long long* gbase_hi;    // [256] where each value of the upper digit starts in the sweep's output
+  const unsigned long long* chain_cnt;   // chain mode: the upper digit's counts over each chain's input range, row c at c * chain_cnt_stride
+  unsigned chain_cnt_stride;
+  unsigned chain_tiles;                  // tiles per chain; 0 = one chain over all tiles
+  unsigned tile;                         // keys per tile of that sweep
+  unsigned n;
+  int shift_hi;                          // bit position of the upper digit
+  unsigned* start;                       // out: [65537], group g = hi * 256 + lo; start[65536] = n
+};
+
+__global__ __launch_bounds__(kRadix) void group_table_kernel(TableArgs a) {
+  __shared__ unsigned part[kRadix];
+  const unsigned lo = blockIdx.x, hi = threadIdx.x;
+  const unsigned long long pos64 = a.gbase_lo[lo];
+  part[hi] = 0;
+  __syncthreads();
+  unsigned result;
+  if (pos64 >= a.n) {                                   // (workgroup-uniform) no key at or behind this boundary: the group is empty
+    result = hi == kRadix - 1 ? a.n : static_cast<unsigned>(a.gbase_hi[hi + 1]);
+  } else {
+    const unsigned pos = static_cast<unsigned>(pos64);
+    const unsigned t = pos / a.tile, r = pos - t * a.tile;
+    const uint32_t* kin = a.keys_in + static_cast<size_t>(t) * a.tile;
+    for (unsigned i = hi; i < r; i += kRadix) atomicAdd(&part[(kin[i] >> a.shift_hi) & 0xFFu], 1u);
+    __syncthreads();
+    const unsigned chain = a.chain_tiles ? t / a.chain_tiles : 0u;
+    const unsigned first = chain * a.chain_tiles;
+    unsigned long long c = a.gbase_hi[hi] + part[hi];
+    for (unsigned x = 0; x < chain; ++x) c += a.chain_cnt[static_cast<size_t>(x) * a.chain_cnt_stride + hi];
+    if (t > first) c += a.desc[static_cast<size_t>(t - 1) * kRadix + hi] & Desc<uint32_t>::kValueMask;
+    result = static_cast<unsigned>(c);
+  }
+  a.start[hi * kRadix + lo] = result;
+  if (lo == 0 && hi == 0) a.start[kRadix * kRadix] = a.n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Groups that do not fit the LDS window
+// ------------------------------------------------------------------------------------------------
+// One workgroup per listed group: an LSD sort of the group's low bits through global memory, tile after tile (the tile
+// part of the sweep: rank inside the wave by returning adds, prefix over the waves, scatter; the running digit offsets
+// stay in LDS, so there is no look-back).  Passes go keys -> alt -> keys; an odd number of passes ends with a copy back.
+// What one pass wrote is read by the next through L1-bypassing loads (another workgroup on this CU may have cached a line
+// that this group shares with its neighbour before this workgroup wrote its part of it).
+struct BigArgs {
+  void* keys;
+  void* alt;
+  const unsigned* start;
+  const unsigned* big_list;      // [0] = count, [1..] = group numbers
+  unsigned big_cap;
+  int low_bits;
+  uint64_t fmask_out, smask_out;
+};
+
+template <typename K, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void group_big_kernel(BigArgs a) {
+  constexpr int WAVES = BLOCK / kWave;
+  constexpr unsigned TILE = BLOCK * ITEMS;
+  __shared__ alignas(16) unsigned base[kRadix];
+  __shared__ unsigned whist[WAVES][kRadix];
+  const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const K fmo = static_cast<K>(a.fmask_out), smo = static_cast<K>(a.smask_out);
+  const unsigned listed = min(a.big_list[0], a.big_cap);
+  const int passes = (a.low_bits + kRadixBits - 1) / kRadixBits;
+  auto load = [](const K* p, bool coherent) -> K {
+    return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+  };
+  for (unsigned e = blockIdx.x; e < listed; e += gridDim.x) {
+    const unsigned g = a.big_list[1 + e];
+    const unsigned gs = a.start[g], len = a.start[g + 1] - gs;
+    K* src = static_cast<K*>(a.keys) + gs;
+    K* dst = static_cast<K*>(a.alt) + gs;
+    for (int p = 0; p < passes; ++p) {
+      const int shift = p * kRadixBits;
+      const int bits = a.low_bits - shift < kRadixBits ? a.low_bits - shift : kRadixBits;
+      const bool coherent = p > 0;
+      const bool last = p == passes - 1 && (passes & 1) == 0;      // this pass writes the final place
+      if (tid < kRadix) base[tid] = 0;
+      __syncthreads();
+      for (unsigned i = tid; i < len; i += BLOCK) atomicAdd(&base[digit_at(load(src + i, coherent), shift, bits)], 1u);
+      __syncthreads();
+      if (wave == 0) {                        // exclusive scan, four digits per lane
+        const uint4 c = reinterpret_cast<const uint4*>(base)[lane];
+        const unsigned sum = c.x + c.y + c.z + c.w;
+        unsigned inc = sum;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+          const unsigned u = __shfl_up(inc, off, kWave);
+          if (lane >= static_cast<unsigned>(off)) inc += u;
+        }
+        unsigned b = inc - sum;
+        uint4 o;
+        o.x = b; b += c.x; o.y = b; b += c.y; o.z = b; b += c.z; o.w = b;
+        reinterpret_cast<uint4*>(base)[lane] = o;
+      }
+      __syncthreads();
+      for (unsigned t0 = 0; t0 < len; t0 += TILE) {
+#pragma unroll
+        for (int i = 0; i < kRadix / kWave; ++i) whist[wave][i * kWave + lane] = 0;
+        K key[ITEMS];
+        unsigned rank[ITEMS];
+        const unsigned seg = t0 + wave * (kWave * ITEMS) + lane;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+          const unsigned idx = seg + i * kWave;
+          key[i] = idx < len ? load(src + idx, coherent) : static_cast<K>(0);
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+          rank[i] = 0;
+          if (seg + i * kWave < len) rank[i] = rank_add<true>(whist[wave], digit_at(key[i], shift, bits));
+        }
+        __syncthreads();
+        if (tid < kRadix) {
+          unsigned sum = base[tid];
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) {
+            const unsigned c = whist[w][tid];
+            whist[w][tid] = sum;
+            sum += c;
+          }
+          base[tid] = sum;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+          if (seg + i * kWave < len) {
+            const unsigned o = whist[wave][digit_at(key[i], shift, bits)] + rank[i];
+            if (o < len) dst[o] = last ? xf_inverse(key[i], fmo, smo) : key[i];
+          }
+        }
+        __syncthreads();
+      }
+      __threadfence();
+      __syncthreads();
+      K* t = src; src = dst; dst = t;
+    }
+    if (passes & 1) {                          // the result sits in alt: back to keys (src and dst have swapped roles)
+      for (unsigned i = tid; i < len; i += BLOCK) dst[i] = xf_inverse(load(src + i, true), fmo, smo);
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace rsk

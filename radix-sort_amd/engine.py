@@ -72,6 +72,10 @@ class Engine:
     def set_tile_order(self, per_xcd: bool):
         self._ck(self.lib.rs_ctx_set_tile_order(self.h, int(per_xcd)))
 
+    def set_hybrid(self, mode: int):
+        """Hybrid form of 4-byte key sorts: -1 chosen per sort (default), 0 never, 1 whenever the key shape allows."""
+        self._ck(self.lib.rs_ctx_set_hybrid(self.h, int(mode)))
+
     def set_host_threads(self, threads: int):
         """Threads the host-buffer entry points may use for the transfers (default 1; at most 4 are used)."""
         self._ck(self.lib.rs_ctx_set_host_threads(self.h, int(threads)))
