@@ -1149,39 +1149,39 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
   const unsigned sw_t = tid ^ (tid >> 6);
   K wk[ITEMS];
   D wo[ITEMS];
-  // Counting kernels add every key to its (chain of the output position, next digit) cell.  PEEL selects how: 0 = one LDS
-  // add per key, straight-line code; 2 = the lanes that share the first lane's cell add once, through that lane, and so do
-  // the lanes that share the first remaining lane's cell.  The staged keys are in digit order, so on few-valued inputs the
-  // 64 lanes of a round hold one or two runs of EQUAL keys and would otherwise queue their adds on one or two words
-  // (256-value duplicates: 4.8 ms per uint32 pass instead of 2.1); on random keys the extra instructions cost 8 % of a
-  // pass, so every wave looks at its first round and picks the form for the other fifteen.
-  unsigned first_group = 0;          // lanes that shared the first lane's cell in round 0
-  auto count_round = [&](auto peel_tag, int i) {
-    constexpr int PEEL = decltype(peel_tag)::value;
+  // Counting kernels add every key to its (chain of the output position, next digit) cell.  RUNS selects how: false = one
+  // LDS add per key, straight-line code; true = by run heads: the staged keys are in digit order, so on ordered inputs the
+  // 64 lanes of a round hold a few CONTIGUOUS runs of keys that share their cell (a sorted ramp: one run; nearly sorted: the
+  // ramp's run, cut here and there by a displaced key), and 64 single adds would queue on one LDS word.  The first lane of
+  // every run adds the run's length and the others add nothing -- the run-head form of the ranking (rank_add_runs_n)
+  // without its broadcast.  Correct for any cells (64 runs of one: the plain form with more instructions).  The form is
+  // chosen per batch of rounds from the batch's SECOND round (one DPP move, one compare, one count): a wave's rounds are
+  // 512 staged positions apart, and the first and the last round of a tile of a nearly sorted input hold its displaced keys,
+  // one cell each, while the rounds between are one run.  Measured, uint32 N = 2^30, first sweep of the hybrid form on the
+  // nearly sorted shape: 4.15 ms with the earlier two-leader peel chosen per tile from its first round, 2.85 ms with run
+  // heads chosen per batch from its first round; a choice per round costs random keys 0.12 ms per pass (2.11 -> 2.23) and a
+  // group-leader form for few interleaved values did not move the 256-value duplicates shape (2.5-2.9 ms either way).
+  // Needs all 64 lanes (full tiles).
+#ifndef RS_COUNT_RUNS_MAX
+#define RS_COUNT_RUNS_MAX 16
+#endif
+  auto cell_of = [&](int i) -> unsigned {
+    const unsigned dn = digit_at(wk[i], a.next_shift, a.next_bits);
+    const unsigned c = __umul24(static_cast<unsigned>(wo[i] >> a.chunk_shift), a.chunk_mul) >> 16;
+    return (c << 8) | dn;
+  };
+  auto count_round = [&](auto runs_tag, int i) {
+    constexpr bool RUNS = decltype(runs_tag)::value;
     if constexpr (CHAIN && COUNT) if (full || i * BLOCK + tid < tile_count) {
-      const unsigned dn = digit_at(wk[i], a.next_shift, a.next_bits);
-      const unsigned c = __umul24(static_cast<unsigned>(wo[i] >> a.chunk_shift), a.chunk_mul) >> 16;
-      if constexpr (PEEL == 0) {
+      const unsigned cell = cell_of(i);
+      const unsigned c = cell >> 8, dn = cell & 0xFFu;
+      if constexpr (!RUNS) {
         atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], 1u << ((c & 1u) << 4));
       } else {
-        const unsigned cell = (c << 8) | dn;
-        const unsigned long long act = __ballot(true);
-        const unsigned l0 = static_cast<unsigned>(__ffsll(static_cast<long long>(act)) - 1);
-        const unsigned cell0 = __builtin_amdgcn_readfirstlane(cell);
-        const unsigned long long g0 = __ballot(cell == cell0);
-        if constexpr (PEEL == 1) first_group = static_cast<unsigned>(__popcll(g0));   // round 0: measure, add one by one
-        unsigned add = 1u;
-        if constexpr (PEEL == 2) {
-          if (cell == cell0) add = lane == l0 ? static_cast<unsigned>(__popcll(g0)) : 0u;
-          const unsigned long long rest = act & ~g0;
-          if (rest) {                                   // wave-uniform
-            const unsigned l1 = static_cast<unsigned>(__ffsll(static_cast<long long>(rest)) - 1);
-            const unsigned cell1 = __builtin_amdgcn_readlane(cell, l1);
-            const unsigned long long g1 = __ballot(cell == cell1);
-            if (cell == cell1) add = lane == l1 ? static_cast<unsigned>(__popcll(g1)) : 0u;
-          }
-        }
-        if (add) atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], add << ((c & 1u) << 4));
+        const unsigned long long heads = __ballot(digit_of_lane_below(cell) != cell);      // lane 0 always
+        const unsigned long long above = lane == 63u ? 0ull : heads >> (lane + 1u);
+        const unsigned run_end = above ? lane + static_cast<unsigned>(__ffsll(static_cast<long long>(above))) : 64u;   // next head, or one past the wave
+        if ((heads >> lane) & 1ull) atomicAdd(&cs.ccnt[((c >> 1) << 8) | dn], (run_end - lane) << ((c & 1u) << 4));
       }
     }
   };
@@ -1191,7 +1191,9 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
 #endif
   constexpr int WB = RS_WOUT_BATCH < ITEMS ? RS_WOUT_BATCH : ITEMS;
   static_assert(ITEMS % WB == 0, "write-out batches");
-  bool few = false;                  // few-valued tile: the counting adds go through group leaders (wave-uniform)
+#ifndef RS_COUNT_RUNS_MAX
+#define RS_COUNT_RUNS_MAX 16
+#endif
 #pragma unroll
   for (int b0 = 0; b0 < ITEMS; b0 += WB) {
 #pragma unroll
@@ -1205,20 +1207,17 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
       if (full || j < tile_count) wo[i] = s.gofs[digit_at(wk[i], a.shift, a.bits)] + j;
     }
     if constexpr (CHAIN && COUNT) {
-      int first = b0;
-      if constexpr (full) {
-        if (b0 == 0) {
-          count_round(std::integral_constant<int, 1>{}, 0);
-          few = __builtin_amdgcn_readfirstlane(first_group) >= 8;
-          first = 1;
-        }
+      bool runs = false;                 // (wave-uniform)
+      if constexpr (full && WB >= 2) {
+        const unsigned cell = cell_of(b0 + 1);
+        runs = __popcll(__ballot(digit_of_lane_below(cell) != cell)) <= RS_COUNT_RUNS_MAX;
       }
-      if (few) {
+      if (runs) {
 #pragma unroll
-        for (int i = first; i < b0 + WB; ++i) count_round(std::integral_constant<int, 2>{}, i);
+        for (int i = b0; i < b0 + WB; ++i) count_round(std::true_type{}, i);
       } else {
 #pragma unroll
-        for (int i = first; i < b0 + WB; ++i) count_round(std::integral_constant<int, 0>{}, i);
+        for (int i = b0; i < b0 + WB; ++i) count_round(std::false_type{}, i);
       }
     }
     if (xf_out) {                                      // workgroup-uniform: the last launched pass only
