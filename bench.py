@@ -95,7 +95,8 @@ def bench_single(args):
 
             def timed(precheck):
                 eng.set_precheck(precheck)
-                times, pass_ms, hist_ms = [], [], []
+                times, pass_ms, hist_ms, group_ms = [], [], [], []
+                hybrid = False
                 for it in range(warmup + steps):
                     work.copy_(src)
                     torch.cuda.synchronize()
@@ -106,13 +107,18 @@ def bench_single(args):
                     if it >= warmup:
                         times.append(t1 - t0)
                         prof = eng.profile()          # empty when the order pre-check answered the call
-                        if prof:
+                        hybrid = bool(eng.lib.rs_debug_last_hybrid(eng.h))
+                        if prof and hybrid:           # [histogram, sweep, sweep, group table + group sort, big-group kernel]
+                            hist_ms.append(prof[0])
+                            pass_ms.extend(prof[1:3])
+                            group_ms.append(sum(prof[3:]))
+                        elif prof:
                             hist_ms.append(prof[0])
                             pass_ms.extend(prof[1:])
-                return times, pass_ms, hist_ms
+                return times, pass_ms, hist_ms, group_ms, hybrid
 
             # product behaviour: order pre-check on (the reference's isSortedBi fast exits, radix_sort.hpp:269-305)
-            times, pass_ms, hist_ms = timed(True)
+            times, pass_ms, hist_ms, group_ms, hybrid = timed(True)
             full = None
             if not pass_ms:                           # ordered input: also time the sort engine proper
                 full = timed(False)
@@ -129,16 +135,27 @@ def bench_single(args):
             del okey
             sec = sum(times) / len(times)
             b_key = algorithmic_bytes_per_key(kb)
+
+            def form_of(hyb, group):
+                """What ran, and the bytes per key it moves by design (SURVEY 8d asks for both: the fraction is priced
+                against the canonical 8-bit LSD bytes whatever form ran).  Hybrid form of 4-byte keys: histogram read K,
+                two sweeps 2 * 2K, one in-LDS group sort 2K = 7K = 28 bytes."""
+                if not hyb:
+                    return {"form": "lsd", "bytes_moved_per_key": b_key}
+                return {"form": "hybrid: 2 onesweep passes on the top digits + in-LDS sort of every 16-bit group",
+                        "bytes_moved_per_key": 7 * kb, "group_ms": sum(group) / len(group) if group else None}
+
             row = {"type": name, "shape": shape, "n": n, "ms": sec * 1e3, "gkeys_s": n / sec / 1e9,
                    "hbm_frac": n * b_key / sec / 1e9 / HBM_PEAK_GBS if pass_ms else None,   # no sort traffic moved when the pre-check answers
-                   "answered_by_precheck": not pass_ms,
+                   "answered_by_precheck": not pass_ms, **(form_of(hybrid, group_ms) if pass_ms else {}),
                    "hist_ms": sum(hist_ms) / len(hist_ms) if hist_ms else None,
                    "pass_ms": sum(pass_ms) / len(pass_ms) if pass_ms else None,
                    "sorted": sorted_ok, "checksum": sum_ok}
             if full is not None:
                 fsec = sum(full[0]) / len(full[0])
                 row["full_sort"] = {"ms": fsec * 1e3, "gkeys_s": n / fsec / 1e9, "hbm_frac": n * b_key / fsec / 1e9 / HBM_PEAK_GBS,
-                                    "hist_ms": sum(full[2]) / len(full[2]), "pass_ms": sum(full[1]) / len(full[1])}
+                                    "hist_ms": sum(full[2]) / len(full[2]), "pass_ms": sum(full[1]) / len(full[1]),
+                                    **form_of(full[4], full[3])}
             rows.append(row)
             if headline is None:
                 headline = row
@@ -148,7 +165,12 @@ def bench_single(args):
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": load_traffic(name),
                             "bytes_per_launch": n * 2 * kb, "avg_launch_ms": avg_pass * 1e3,
-                            "whole_sort_frac": row["hbm_frac"] if row["hbm_frac"] else row["full_sort"]["hbm_frac"]}
+                            "whole_sort_frac": row["hbm_frac"] if row["hbm_frac"] else row["full_sort"]["hbm_frac"],
+                            "whole_sort_bytes_moved_per_key": row.get("bytes_moved_per_key") or row["full_sort"].get("bytes_moved_per_key")}
+                gms = row.get("group_ms") or (row.get("full_sort") or {}).get("group_ms")
+                if gms:     # the hybrid form's second kernel: one read + one write of the keys per launch
+                    dominant["group_sort_kernel"] = {"bytes_per_launch": n * 2 * kb, "avg_launch_ms": gms,
+                                                     "achieved": n * 2 * kb / (gms * 1e-3) / 1e9, "frac": n * 2 * kb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             del src
         del work, alt
         torch.cuda.empty_cache()
@@ -325,7 +347,8 @@ def main():
         "value": headline["gkeys_s"], "unit": "Gkeys/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": headline["ms"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": headline["type"], "data": "synthetic",
-        "config": {"workload": f"{headline['type']} {headline['shape']} N={headline['n']} keys-only LSD onesweep, "
+        "config": {"workload": f"{headline['type']} {headline['shape']} N={headline['n']} keys-only sort "
+                               f"({headline.get('form') or headline['full_sort'].get('form')}), "
                                "device-resident (BASELINE configs[1]); all (type, shape) rows in `rows`"},
         "roofline": roof,
         "rows": rows,

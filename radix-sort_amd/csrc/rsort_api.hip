@@ -84,7 +84,7 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // where it pays -- sorts of at least this many tiles (16 M four-byte keys), which saturate the GPU on their own -- and
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
-constexpr size_t kHybridMinKeys = size_t(1) << 25;   // hybrid form of 4-byte key sorts from here on (below, its 65536 workgroups cost more than two sweeps)
+constexpr size_t kHybridMinKeys = 120000000;   // hybrid form of 4-byte key sorts from here on (measured: 2^27 keys 1.19 against 1.34 ms, 2^26 keys 0.77 against 0.67 -- below, the fixed cost of 65536 workgroups outweighs the two sweeps saved)
 constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) neither pass skipping nor the order pre-check is worth a host synchronisation
 
 // Hybrid sort of 4-byte keys (rsort_groups.hpp): two sweeps on the top digits, then every group of equal top 16 bits is
@@ -707,7 +707,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     ga.fmask_out = fmask; ga.smask_out = smask;
     ga.big_list = big_list; ga.big_cap = kGroupCount;
     ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, kGroupBlock * kGroupMaxVec) : kGroupBlock * kGroupMaxVec;
-    hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 2>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
+    hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     rsk::BigArgs ba{};
     ba.keys = keys; ba.alt = alt_keys; ba.start = start; ba.big_list = big_list; ba.big_cap = kGroupCount; ba.low_bits = 16;

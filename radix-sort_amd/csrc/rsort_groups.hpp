@@ -51,6 +51,18 @@ struct GroupSmem {
 // The window is the 16-byte aligned range of the array that covers the group; window elements outside the group and the
 // elements of vectors beyond the window are "pads": they take the largest value, sort behind every real key and are never
 // stored.  Real key of final rank j lands at window element head + j, so the store phase writes whole aligned vectors.
+// Staging-area swizzle: value number p lives at element p ^ ((((p >> 6) ^ (p >> 10)) & 15) << 2), i.e. inside every aligned
+// block of 64 elements (128 bytes) the 8-byte pieces are permuted by a hash of the block's number (bits 6-9 for runs of 64,
+// the second pass of a ramp; bits 10-13 as well for runs of 256, its first pass).  On a ramp (nearly sorted input: a group is
+// 16384 consecutive multiples of 4) every digit's run has the same power-of-two length, so the lanes of one scatter store
+// -- same rank, neighbouring digits -- would all fall on one LDS bank (measured: 3.7 ms for the ramp against 2.4 ms for
+// random keys at N = 2^30).  Aligned groups of four elements stay together, so the store phase still reads 8 bytes per lane.
+__device__ __forceinline__ unsigned group_swizzle(unsigned p) { return p ^ ((((p >> 6) ^ (p >> 10)) & 15u) << 2); }
+
+// Cell of digit d in the shared counter table of the first pass: d ^ (d >> 4).  A bijection on 0..255 that spreads digits
+// a multiple of 16 apart (what the lanes of one instruction hold when the group is a ramp of step 4) over the banks.
+__device__ __forceinline__ unsigned group_cell(unsigned d) { return d ^ (d >> 4); }
+
 template <typename K, int BLOCK, int MAXV, int IT>
 __device__ __forceinline__ void group_sort_body(GroupSmem<BLOCK, MAXV>& s, K* win, unsigned head, unsigned len, unsigned nvec,
                                                 K top, int low_bits, K fmo, K smo) {
@@ -61,13 +73,16 @@ __device__ __forceinline__ void group_sort_body(GroupSmem<BLOCK, MAXV>& s, K* wi
   const bool two = low_bits > kRadixBits;
 
   // ---- load: 16 bytes per lane, consecutive lanes consecutive vectors --------------------------------
+  // Vector k of a thread is window vector k * BLOCK + tid.  With IT = ceil(nvec / BLOCK), the vectors of rounds 1 .. IT - 2
+  // lie wholly inside the group; only round 0 (the window's first vector may begin before the group) and round IT - 1 (the
+  // window ends inside it) hold elements that do not belong to the group.  Those are simply left out of the sort.
   const uint4* wv = reinterpret_cast<const uint4*>(win);
   uint4 x[IT];
 #pragma unroll
   for (int k = 0; k < IT; ++k) {
     const unsigned v = k * BLOCK + tid;
-    x[k] = uint4{~0u, ~0u, ~0u, ~0u};
-    if (!(RS_GROUP_ABL & 16) && v < nvec) x[k] = wv[v];
+    x[k] = uint4{0u, 0u, 0u, 0u};
+    if (!(RS_GROUP_ABL & 16) && (k < IT - 1 || v < nvec)) x[k] = wv[v];
     if (RS_GROUP_ABL & 16) x[k] = uint4{v * 2654435761u, v * 40503u, v ^ 0x5bd1e995u, v * 7u};
   }
   if (tid < kRadix) s.hist[tid] = 0;
@@ -76,28 +91,53 @@ __device__ __forceinline__ void group_sort_body(GroupSmem<BLOCK, MAXV>& s, K* wi
   __syncthreads();
 
   // ---- pass 1, bits 0-7: count (any order will do) ---------------------------------------------------
+  // A lane takes the four keys of a vector in an order rotated by its row of 16 lanes: when the group is a ramp whose
+  // low digit repeats every 16 lanes, the four lanes that would share a counter in one instruction then hold four different digits.
+  const unsigned rot = (lane >> 4) & 3u;
   unsigned lo[2 * IT];          // two 16-bit values per register
+  unsigned ok[IT];              // bit c: element c of the vector (in the rotated order) belongs to the group; rounds 0 and IT - 1 only
 #pragma unroll
   for (int k = 0; k < IT; ++k) {
-    const unsigned e = 4u * (k * BLOCK + tid) - head;       // rank of x[k].x inside the group if it belongs to it (wraps below head)
-    const unsigned a0 = e < len ? x[k].x & lowmask : lowmask;
-    const unsigned a1 = e + 1u < len ? x[k].y & lowmask : lowmask;
-    const unsigned a2 = e + 2u < len ? x[k].z & lowmask : lowmask;
-    const unsigned a3 = e + 3u < len ? x[k].w & lowmask : lowmask;
-    if (!(RS_GROUP_ABL & 1)) {
-      atomicAdd(&s.hist[a0 & 255u], 1u);
-      atomicAdd(&s.hist[a1 & 255u], 1u);
-      atomicAdd(&s.hist[a2 & 255u], 1u);
-      atomicAdd(&s.hist[a3 & 255u], 1u);
-    }
+    const unsigned a = x[k].x & lowmask, b = x[k].y & lowmask, c = x[k].z & lowmask, d = x[k].w & lowmask;
+    // rotate (a, b, c, d) left by rot
+    const unsigned r0 = rot & 1u ? b : a, r1 = rot & 1u ? c : b, r2 = rot & 1u ? d : c, r3 = rot & 1u ? a : d;
+    const unsigned a0 = rot & 2u ? r2 : r0, a1 = rot & 2u ? r3 : r1, a2 = rot & 2u ? r0 : r2, a3 = rot & 2u ? r1 : r3;
     lo[2 * k] = a0 | (a1 << 16);
     lo[2 * k + 1] = a2 | (a3 << 16);
+    if (k == 0 || k == IT - 1) {
+      const unsigned e = 4u * (k * BLOCK + tid) - head;     // rank of x[k].x inside the group if it belongs to it (wraps below head)
+      unsigned m = 0;
+#pragma unroll
+      for (unsigned j = 0; j < 4; ++j) m |= (e + ((j + rot) & 3u) < len ? 1u : 0u) << j;
+      ok[k] = m;
+      if (!(RS_GROUP_ABL & 1)) {
+        if (m & 1u) atomicAdd(&s.hist[group_cell(a0 & 255u)], 1u);
+        if (m & 2u) atomicAdd(&s.hist[group_cell(a1 & 255u)], 1u);
+        if (m & 4u) atomicAdd(&s.hist[group_cell(a2 & 255u)], 1u);
+        if (m & 8u) atomicAdd(&s.hist[group_cell(a3 & 255u)], 1u);
+      }
+    } else if (!(RS_GROUP_ABL & 1)) {
+      atomicAdd(&s.hist[group_cell(a0 & 255u)], 1u);
+      atomicAdd(&s.hist[group_cell(a1 & 255u)], 1u);
+      atomicAdd(&s.hist[group_cell(a2 & 255u)], 1u);
+      atomicAdd(&s.hist[group_cell(a3 & 255u)], 1u);
+    }
   }
   __syncthreads();
-  // exclusive scan of the 256 counts by one wave, four digits per lane
+  // exclusive scan of the 256 counts in digit order by one wave, four digits per lane.  Digits 4 * lane .. 4 * lane + 3 share
+  // their high nibble, so their cells are the aligned group of four at (4 * lane) ^ (high nibble & 12), permuted inside it by
+  // the high nibble's low two bits.
   if (wave == 0) {
-    const uint4 c = reinterpret_cast<const uint4*>(s.hist)[lane];
-    const unsigned sum = c.x + c.y + c.z + c.w;
+    const unsigned hn = lane >> 2;                         // high nibble of the lane's digits
+    uint4 c = reinterpret_cast<const uint4*>(s.hist)[lane ^ (hn >> 2)];
+    unsigned q[4] = {c.x, c.y, c.z, c.w};
+    unsigned cnt[4];
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) {                     // count of digit 4 * lane + j sits at component j ^ (hn & 3)
+      const unsigned i = j ^ (hn & 3u);
+      cnt[j] = i == 0 ? q[0] : i == 1 ? q[1] : i == 2 ? q[2] : q[3];
+    }
+    const unsigned sum = cnt[0] + cnt[1] + cnt[2] + cnt[3];
     unsigned inc = sum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -105,41 +145,79 @@ __device__ __forceinline__ void group_sort_body(GroupSmem<BLOCK, MAXV>& s, K* wi
       if (lane >= static_cast<unsigned>(off)) inc += u;
     }
     unsigned b = inc - sum + (two ? 0u : head);            // (a single pass scatters straight to the store layout)
-    uint4 o;
-    o.x = b; b += c.x; o.y = b; b += c.y; o.z = b; b += c.z; o.w = b;
-    reinterpret_cast<uint4*>(s.hist)[lane] = o;
+    unsigned o[4];
+#pragma unroll
+    for (unsigned j = 0; j < 4; ++j) { o[j] = b; b += cnt[j]; }
+    unsigned w[4];
+#pragma unroll
+    for (unsigned i = 0; i < 4; ++i) {                     // component i holds digit 4 * lane + (i ^ (hn & 3))
+      const unsigned j = i ^ (hn & 3u);
+      w[i] = j == 0 ? o[0] : j == 1 ? o[1] : j == 2 ? o[2] : o[3];
+    }
+    reinterpret_cast<uint4*>(s.hist)[lane ^ (hn >> 2)] = uint4{w[0], w[1], w[2], w[3]};
   }
   __syncthreads();
   // scatter: a returning add on the digit's cursor hands out the slots of its run (eight keys at a time: registers)
   {
-    constexpr int SB = 2 * IT % 4 == 0 ? 4 : 2 * IT % 2 == 0 ? 2 : 1;   // registers of lo[] per batch
+    auto scatter = [&](auto first_tag, auto count_tag, auto pred_tag) {
+      constexpr int B0 = decltype(first_tag)::value, NB = decltype(count_tag)::value;
+      constexpr bool PRED = decltype(pred_tag)::value;
+      unsigned pos[2 * NB];
 #pragma unroll
-    for (int b = 0; b < 2 * IT; b += SB) {
-      unsigned pos[2 * SB];
-#pragma unroll
-      for (int k = 0; k < SB; ++k) {
-        if (RS_GROUP_ABL & 2) { pos[2 * k] = 4u * ((b + k) / 2 * BLOCK + tid) + 2 * ((b + k) & 1); pos[2 * k + 1] = pos[2 * k] + 1; continue; }
-        pos[2 * k] = atomicAdd(&s.hist[lo[b + k] & 255u], 1u);
-        pos[2 * k + 1] = atomicAdd(&s.hist[(lo[b + k] >> 16) & 255u], 1u);
+      for (int k = 0; k < NB; ++k) {
+        const unsigned m = PRED ? ok[(B0 + k) / 2] >> (2 * ((B0 + k) & 1)) : 3u;
+        pos[2 * k] = pos[2 * k + 1] = 0;
+        if (RS_GROUP_ABL & 2) { pos[2 * k] = 4u * ((B0 + k) / 2 * BLOCK + tid) + 2 * ((B0 + k) & 1); pos[2 * k + 1] = pos[2 * k] + 1; continue; }
+        if (!PRED || (m & 1u)) pos[2 * k] = atomicAdd(&s.hist[group_cell(lo[B0 + k] & 255u)], 1u);
+        if (!PRED || (m & 2u)) pos[2 * k + 1] = atomicAdd(&s.hist[group_cell((lo[B0 + k] >> 16) & 255u)], 1u);
       }
 #pragma unroll
-      for (int k = 0; k < SB; ++k) {
-        s.val[pos[2 * k]] = static_cast<unsigned short>(lo[b + k]);
-        s.val[pos[2 * k + 1]] = static_cast<unsigned short>(lo[b + k] >> 16);
+      for (int k = 0; k < NB; ++k) {
+        const unsigned m = PRED ? ok[(B0 + k) / 2] >> (2 * ((B0 + k) & 1)) : 3u;
+        if (!PRED || (m & 1u)) s.val[group_swizzle(pos[2 * k])] = static_cast<unsigned short>(lo[B0 + k]);
+        if (!PRED || (m & 2u)) s.val[group_swizzle(pos[2 * k + 1])] = static_cast<unsigned short>(lo[B0 + k] >> 16);
       }
+    };
+    // round 0, then the inner rounds in batches of two vectors, then round IT - 1
+    scatter(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::true_type{});
+    if constexpr (IT > 2) {
+      constexpr int INNER = 2 * (IT - 2);                 // registers of lo[]
+      auto inner = [&](auto self, auto at_tag) {
+        constexpr int AT = decltype(at_tag)::value;
+        if constexpr (AT < 2 + INNER) {
+          constexpr int NB = 2 + INNER - AT >= 4 ? 4 : 2;
+          scatter(std::integral_constant<int, AT>{}, std::integral_constant<int, NB>{}, std::false_type{});
+          self(self, std::integral_constant<int, AT + NB>{});
+        }
+      };
+      inner(inner, std::integral_constant<int, 2>{});
     }
+    if constexpr (IT > 1) scatter(std::integral_constant<int, 2 * (IT - 1)>{}, std::integral_constant<int, 2>{}, std::true_type{});
   }
   __syncthreads();
 
   // ---- pass 2, bits 8-15: stable with respect to the order pass 1 left --------------------------------
   if (two && !(RS_GROUP_ABL & 4)) {                           // workgroup-uniform
     constexpr int R = 4 * IT;                                 // rounds of 64 per wave
-    const unsigned segbase = wave * (R * kWave) + lane;
+    const unsigned segfirst = wave * (R * kWave);             // the wave's segment of the order pass 1 left: [segfirst, segfirst + R * 64)
+    const unsigned segbase = segfirst + lane;
     unsigned kr[R];                                           // value | rank << 16
+    const bool whole = segfirst + R * kWave <= len;           // (wave-uniform) every position of the segment holds a key
+    if (whole) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) kr[r] = s.val[segbase + r * kWave];
+      for (int r = 0; r < R; ++r) kr[r] = s.val[group_swizzle(segbase + r * kWave)];
 #pragma unroll
-    for (int r = 0; r < R; ++r) kr[r] |= rank_add<true>(s.whist[wave], kr[r] >> 8) << 16;
+      for (int r = 0; r < R; ++r) kr[r] |= rank_add<true>(s.whist[wave], kr[r] >> 8) << 16;
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        kr[r] = 0;
+        if (segbase + r * kWave < len) {
+          kr[r] = s.val[group_swizzle(segbase + r * kWave)];
+          kr[r] |= rank_add<true>(s.whist[wave], kr[r] >> 8) << 16;
+        }
+      }
+    }
     __syncthreads();
     unsigned my_count = 0, inc = 0;
     if (tid < kRadix) {
@@ -166,13 +244,20 @@ __device__ __forceinline__ void group_sort_body(GroupSmem<BLOCK, MAXV>& s, K* wi
       }
     }
     __syncthreads();
+    if (whole) {
 #pragma unroll
-    for (int b = 0; b < R; b += 4) {
-      unsigned pos[4];
+      for (int b = 0; b < R; b += 4) {
+        unsigned pos[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) pos[r] = s.whist[wave][(kr[b + r] >> 8) & 255u] + (kr[b + r] >> 16);
+        for (int r = 0; r < 4; ++r) pos[r] = s.whist[wave][(kr[b + r] >> 8) & 255u] + (kr[b + r] >> 16);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s.val[pos[r]] = static_cast<unsigned short>(kr[b + r]);
+        for (int r = 0; r < 4; ++r) s.val[group_swizzle(pos[r])] = static_cast<unsigned short>(kr[b + r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (segbase + r * kWave < len)
+          s.val[group_swizzle(s.whist[wave][(kr[r] >> 8) & 255u] + (kr[r] >> 16))] = static_cast<unsigned short>(kr[r]);
     }
     __syncthreads();
   }
@@ -182,12 +267,12 @@ __device__ __forceinline__ void group_sort_body(GroupSmem<BLOCK, MAXV>& s, K* wi
 #pragma unroll
   for (int k = 0; k < IT; ++k) {
     const unsigned v = k * BLOCK + tid;
-    if (v < nvec && !(RS_GROUP_ABL & 8)) {
-      const uint2 p = reinterpret_cast<const uint2*>(s.val)[v];
+    if ((k < IT - 1 || v < nvec) && !(RS_GROUP_ABL & 8)) {
+      const uint2 p = reinterpret_cast<const uint2*>(s.val)[v ^ (((v >> 4) ^ (v >> 8)) & 15u)];      // group_swizzle(4 * v) / 4
       K o0 = top | (p.x & 0xFFFFu), o1 = top | (p.x >> 16), o2 = top | (p.y & 0xFFFFu), o3 = top | (p.y >> 16);
       if (xf_out) { o0 = xf_inverse(o0, fmo, smo); o1 = xf_inverse(o1, fmo, smo); o2 = xf_inverse(o2, fmo, smo); o3 = xf_inverse(o3, fmo, smo); }
       const unsigned e = 4u * v - head;
-      if (4u * v >= head && e + 3u < len) {
+      if ((k > 0 && k < IT - 1) || (4u * v >= head && e + 3u < len)) {
         reinterpret_cast<uint4*>(win)[v] = uint4{o0, o1, o2, o3};
       } else {
         if (e < len) win[4u * v] = o0;
