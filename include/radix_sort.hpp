@@ -139,7 +139,7 @@ namespace radix_sort
 			// at most what the hardware has.  Not the reference's "largest power of two <= n / 1,000,000" below the cap: its
 			// threads each own a power-of-two share of the buckets, these only cut [0, n) into ranges, and what they do waits on
 			// memory (10^7 {string; long long} objects: 82 ms end to end with 8 threads, 61 ms with 12).
-			//   transfers: from the reference's 2,000,000 elements on (10^6 unsigned: 0.56 ms with one lane, more with several);
+			//   transfers: from 16 MiB on (hostThreads below; strings: from 2,000,000 strings, the reference's element count, at 8 bytes each);
 			//   packing / gathering strings and objects: from 250,000 on -- starting a dozen threads costs well under a
 			//   millisecond, one thread needs 13-20 ms for 10^6 strings or objects (STRING 10^6: 19.5 -> 7.8 ms).
 			inline std::size_t hostThreadsFrom(std::size_t n, bool enableMultiThreading, std::size_t threshold)
@@ -149,9 +149,12 @@ namespace radix_sort
 				const std::size_t hw = std::max<std::size_t>(1, std::thread::hardware_concurrency());
 				return std::min(hw, std::size_t(12));
 			}
-			inline std::size_t hostThreads(std::size_t n, bool enableMultiThreading)       // transfer lanes
+			// transfer lanes, by the BYTES the largest array of the call moves: the reference's 2,000,000-element threshold is
+			// 8 MB of its headline type; several lanes pay from about 16 MiB on (10^7 one-byte keys: 1.07 ms over one lane,
+			// 3.0 ms over four; 10^7 two-byte keys: 1.85 against 1.52 ms; 10^7 four-byte keys: 3.2 against 2.4 ms)
+			inline std::size_t hostThreads(std::size_t n, bool enableMultiThreading, std::size_t bytesPerElement = 8)
 			{
-				return hostThreadsFrom(n, enableMultiThreading, 2'000'000);
+				return hostThreadsFrom(n * bytesPerElement, enableMultiThreading, std::size_t(16) << 20);
 			}
 			inline std::size_t helperThreads(std::size_t n, bool enableMultiThreading)     // packing, gathering
 			{
@@ -278,8 +281,11 @@ namespace radix_sort
 					constexpr std::size_t kAhead = 16;     // the bytes of a string past the small-string size live somewhere on the heap
 					for (std::size_t i = lo; i < hi; i++)
 					{
-						if (i + kAhead < hi)
-							__builtin_prefetch(std::invoke(proj, v[i + kAhead]).data(), 0, 0);
+						// (only when the projection hands out the object's own string: one returned by value would be built and
+						// destroyed here just to be asked for its address, and would have left that address behind by the copy)
+						if constexpr (std::is_lvalue_reference_v<std::invoke_result_t<Proj&, const T&>>)
+							if (i + kAhead < hi)
+								__builtin_prefetch(std::invoke(proj, v[i + kAhead]).data(), 0, 0);
 						const std::string& s = std::invoke(proj, v[i]);
 						p.offsets[i] = at;
 						std::copy(s.begin(), s.end(), p.blob.data() + at);
@@ -337,7 +343,7 @@ namespace radix_sort
 						"ERROR: Unable to sort vector! CAUSE: std::vector<bool> has no element storage!");
 					device::checkKeyType<T>();
 					rs_ctx* ctx = device::context();
-					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(device::hostThreads(v.size(), enableMultiThreading))));
+					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(device::hostThreads(v.size(), enableMultiThreading, sizeof(T)))));
 					device::check(ctx, rs_sort_keys(ctx, v.data(), v.size(), static_cast<int>(sizeof(T)),
 						device::transformOf<T>(), 0, static_cast<int>(sizeof(T)) * 8));
 				}
@@ -375,7 +381,7 @@ namespace radix_sort
 					});
 
 					rs_ctx* ctx = device::context();
-					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(device::hostThreads(SIZE, enableMultiThreading))));
+					device::check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(device::hostThreads(SIZE, enableMultiThreading, std::max(sizeof(Stored), sizeof(T))))));
 					constexpr int XF = device::transformOf<Key>();
 					constexpr int BITS = static_cast<int>(sizeof(Key)) * 8;
 

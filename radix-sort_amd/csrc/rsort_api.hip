@@ -85,6 +85,8 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
 constexpr size_t kHybridMinKeys = 120000000;   // hybrid form of 4-byte key sorts from here on (measured: 2^27 keys 1.19 against 1.34 ms, 2^26 keys 0.77 against 0.67 -- below, the fixed cost of 65536 workgroups outweighs the two sweeps saved)
+constexpr size_t kHybridMinKeysWide = 400000000;   // the same for 8-byte keys (2^29 keys: 12.8 against 15.0 ms; 2^28: 9.7 against 7.6 -- its 65536 workgroups of 1024 threads
+                                                  // each run six LDS passes whatever the group's size: 5 ms of fixed cost)
 constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) neither pass skipping nor the order pre-check is worth a host synchronisation
 
 // Hybrid sort of 4-byte keys (rsort_groups.hpp): two sweeps on the top digits, then every group of equal top 16 bits is
@@ -92,6 +94,10 @@ constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) n
 constexpr int kGroupBlock = 512;
 constexpr int kGroupMaxVec = 10;
 constexpr size_t kGroupCap = size_t(kGroupBlock) * kGroupMaxVec * 4 - 3;   // keys of the largest group the LDS window holds at any alignment
+// 8-byte keys: whole keys in LDS (rsk::group_sort_wide_kernel), 1024 threads x 17 keys = 17408 keys = 136 KB, one workgroup per CU
+constexpr int kWideGroupBlock = 1024;
+constexpr int kWideGroupItems = 17;
+constexpr size_t kWideGroupCap = size_t(kWideGroupBlock) * kWideGroupItems;
 constexpr unsigned kGroupCount = 65536;
 constexpr size_t kGroupsBytes = (size_t(kGroupCount) + 1 + kGroupCount + 1) * sizeof(unsigned);   // start table + list of oversize groups
 
@@ -113,7 +119,8 @@ struct rs_ctx {
   bool per_xcd_probe_ok = false;     // what the probe found
   int cus = 256;                     // compute units of the device (persistent grids: 2 workgroups each)
   char* static_scratch = nullptr;    // this device's copy of rs_static_scratch (rs_sort_keys_device_noalloc)
-  bool static_used = false;          // a sort has used it since its error word was last read
+  bool static_used = false;          // this context has queued a sort on it (or captured one into a graph that may replay at any time): its error word
+                                     // is read at every synchronisation from then on
   int hist_copy = 0;                 // the copy of the digit counts in `ctrl` that is zero now (kCtrlHist1)
   unsigned* pinned_flags = nullptr;  // two pinned host words the error words are fetched into (a pageable 4-byte copy costs 20 us)
   bool host_call = false;            // sort_device runs inside a host-buffer entry point (which waits for the device anyway)
@@ -124,6 +131,8 @@ struct rs_ctx {
   unsigned group_max_vec = 0;    // test hook: groups of more vectors than this go to the big-group kernel (0 = what the LDS window holds)
   bool last_hybrid = false;      // the last sort_device took the hybrid form
   hipEvent_t ev[kMaxPasses + 2] = {};
+  hipEvent_t small_up = nullptr;     // after the last small host-to-device copy through lane 0's bounce buffer (to_device)
+  bool small_up_pending = false;
   int ev_count = 0;
   rst::Mover mover;        // host <-> HBM legs of the host-buffer entry points (rsort_transfer.hpp)
   struct Fetched { void* host; size_t bytes; } fetched[2] = {{nullptr, 0}, {nullptr, 0}};   // small results waiting in pinned memory
@@ -379,7 +388,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
   // RSORT_FORCE_WIDE=1 (tests, A/B timing): 8-byte descriptors and offsets regardless of n
   static const bool force_wide = [] { const char* e = std::getenv("RSORT_FORCE_WIDE"); return e && e[0] == '1'; }();
-  const bool wide = n > kSmallDescLimit || force_wide;
+  const bool wide = n > kSmallDescLimit || (force_wide && !ws);   // (the static workspace holds 4-byte descriptor rows only, and its n <= 2^25 never needs more)
   // Chain mode (rsort_kernels.hpp, "XCD chains"): one chain of tiles per XCD, swept by persistent workgroups.  For sorts
   // large enough to keep every XCD busy with its own chain, on devices where the XCC-id probe found all eight XCDs, with
   // the returning-add ranking, 4- and 8-byte keys, 16-byte aligned buffers (the histogram kernel counts per chain in
@@ -540,7 +549,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // Chain mode keeps 4-byte descriptors and offsets up to 2^32 keys: a descriptor holds a count inside ONE chain (at most an
   // eighth of the keys plus a tile, below 2^30), and output offsets below 2^32 fit the 4-byte tables.  The one-chain
   // kernels' descriptors hold counts over the whole array and need the 8-byte form from 2^30 keys on.
-  const bool wide_chain = force_wide || n >= (size_t(1) << 32);
+  const bool wide_chain = (force_wide && !ws) || n >= (size_t(1) << 32);
   // (the rows this sort uses, not the whole reservation.  Should the few-valued rule below send a chain-mode sort down the
   // one-chain kernels, those use their own tile size and, beyond 2^30 keys, 8-byte rows: about the same bytes as the 4-byte
   // rows of the 8192-key tiles, but rounded up separately -- ceil(n / 16384) * 8 can exceed ceil(n / 8192) * 4 by one row
@@ -549,6 +558,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // top digit takes few values by construction, hit exactly that.)
   size_t desc_clear = tiles * 256 * ((chain ? wide_chain : wide) ? 8 : 4);
   if (chain) desc_clear = std::max(desc_clear, tiles_for(n, key_bytes, value_bytes, false) * 256 * (wide ? size_t(8) : size_t(4)));
+  if (ws && !mid && desc_clear > kNoAllocDescBytes) return fail(c, RS_ERR_ARG, "descriptor rows exceed the static workspace");   // (cannot happen: n <= kNoAllocMaxKeys, 4-byte rows)
   if (!mid && (rc = clear_async(c, desc, desc_clear, s, capturing)) != RS_OK) return rc;
 
   auto* chain_hist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlChainHist);
@@ -565,6 +575,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     h.zero_vecs[1] = static_cast<unsigned>((kCtrlMidDesc - kCtrlTicket + tiles * 256 * 4) / 16);
   }
   launch_hist(h, key_bytes, chain ? 256u * hist_wgs_per_cu(key_bytes) : hist_grid(n, key_bytes), s);
+  RS_HIP(c, hipGetLastError());         // (a histogram that was not launched has not cleared the other copy of the counts)
   if (self_clearing) c->hist_copy ^= 1;
   if (!in_tile_scan)
     hipLaunchKernelGGL(rsk::digit_scan_kernel, dim3(passes), dim3(rsk::kRadix), 0, s, ghist, gbase,
@@ -629,22 +640,26 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // rs_ctx_set_hybrid / RSORT_HYBRID: 0 never, 1 whenever the shape allows it (tests: any size, any distribution).
   const int hybrid_env = c->hybrid_mode;
   bool hybrid = false;
-  if (hybrid_env != 0 && !ws && !mid && !wide && value_bytes == 0 && key_bytes == 4 && begin_bit == 0 && end_bit == 32 &&
-      n_live == 4 && n < (size_t(1) << 32) && c->rank_by_lds_atomic && (reinterpret_cast<uintptr_t>(keys) & 3u) == 0) {
+  const int top_lo = key_bytes - 2, top_hi = key_bytes - 1;          // the two swept digits
+  const size_t group_cap = key_bytes == 4 ? kGroupCap : kWideGroupCap;
+  if (hybrid_env != 0 && !ws && !mid && !wide && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
+      end_bit == key_bytes * 8 && n_live == key_bytes && n < (size_t(1) << 32) && c->rank_by_lds_atomic &&
+      (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
     if (hybrid_env == 1) {
       hybrid = true;
     } else {
-      unsigned long long mx[4] = {0, 0, 0, 0};
-      for (int p = 0; p < 4; ++p)
+      unsigned long long mx[kMaxPasses] = {};
+      for (int p = 0; p < key_bytes; ++p)
         for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
-      const double bound = static_cast<double>(mx[3]) * static_cast<double>(mx[2]) / static_cast<double>(n);   // largest group if the top digits are independent
-      hybrid = n >= kHybridMinKeys && bound <= 0.95 * kGroupCap && mx[0] <= n / 16 && mx[1] <= n / 16;
+      const double bound = static_cast<double>(mx[top_hi]) * static_cast<double>(mx[top_lo]) / static_cast<double>(n);   // largest group if the top digits are independent
+      hybrid = n >= (key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide) && bound <= 0.95 * group_cap;
+      for (int p = 0; p < top_lo; ++p) hybrid = hybrid && mx[p] <= n / 16;
     }
   }
   if (hybrid) {
     c->last_hybrid = true;
     if ((rc = ensure(c, c->groups, kGroupsBytes)) != RS_OK) return rc;
-    live[0] = 2; live[1] = 3; n_live = 2;
+    live[0] = top_lo; live[1] = top_hi; n_live = 2;
   }
 
   void* kin = keys; void* kout = alt_keys;
@@ -692,27 +707,37 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     RS_HIP(c, hipMemsetAsync(big_list, 0, sizeof(unsigned), s));
     rsk::TableArgs t{};
     t.desc = static_cast<const uint32_t*>(desc);
-    t.keys_in = static_cast<const uint32_t*>(last_sweep.keys_in);
-    t.gbase_lo = gbase + 2 * rsk::kRadix; t.gbase_hi = gbase + 3 * rsk::kRadix;
+    t.keys_in = last_sweep.keys_in;
+    t.gbase_lo = gbase + top_lo * rsk::kRadix; t.gbase_hi = gbase + top_hi * rsk::kRadix;
     t.chain_cnt = sweep_chain ? last_sweep.chain_cnt : nullptr;
     t.chain_cnt_stride = last_sweep.chain_cnt_stride;
     t.chain_tiles = sweep_chain ? chain_tiles : 0u;
     t.tile = static_cast<unsigned>(tile_keys(key_bytes, value_bytes, sweep_chain));
     t.n = static_cast<unsigned>(n);
-    t.shift_hi = 24;
+    t.shift_hi = top_hi * rsk::kRadixBits;
     t.start = start;
-    hipLaunchKernelGGL(rsk::group_table_kernel, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
     rsk::GroupArgs ga{};
-    ga.keys = keys; ga.start = start; ga.groups = kGroupCount; ga.low_bits = 16;
+    ga.keys = keys; ga.start = start; ga.groups = kGroupCount; ga.low_bits = top_lo * rsk::kRadixBits;
     ga.fmask_out = fmask; ga.smask_out = smask;
     ga.big_list = big_list; ga.big_cap = kGroupCount;
-    ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, kGroupBlock * kGroupMaxVec) : kGroupBlock * kGroupMaxVec;
-    hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
-    if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+    ga.n = static_cast<unsigned>(n); ga.error_flag = error_flag;
     rsk::BigArgs ba{};
-    ba.keys = keys; ba.alt = alt_keys; ba.start = start; ba.big_list = big_list; ba.big_cap = kGroupCount; ba.low_bits = 16;
+    ba.keys = keys; ba.alt = alt_keys; ba.start = start; ba.big_list = big_list; ba.big_cap = kGroupCount; ba.low_bits = ga.low_bits;
     ba.fmask_out = fmask; ba.smask_out = smask;
-    hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
+    ba.n = static_cast<unsigned>(n); ba.error_flag = error_flag;
+    if (key_bytes == 4) {
+      hipLaunchKernelGGL(rsk::group_table_kernel<uint32_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
+      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, kGroupBlock * kGroupMaxVec) : kGroupBlock * kGroupMaxVec;
+      hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
+      if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+      hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
+    } else {
+      hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
+      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWideGroupCap) : static_cast<unsigned>(kWideGroupCap);   // (keys, for this kernel)
+      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, kWideGroupBlock, kWideGroupItems>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
+      if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+      hipLaunchKernelGGL((rsk::group_big_kernel<uint64_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
+    }
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
   }
   RS_HIP(c, hipGetLastError());
@@ -736,12 +761,14 @@ int check_kernel_error(rs_ctx* c) {
   if (c->static_used) RS_HIP(c, hipMemcpyAsync(&f[1], c->static_scratch + kCtrlError, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   RS_HIP(c, hipStreamSynchronize(c->stream));      // (also the wait when only single-workgroup sorts ran: no error word yet)
   unsigned flag = f[0], sflag = f[1];
-  c->static_used = false;
   if (flag) RS_HIP(c, hipMemsetAsync(ctrl + kCtrlError, 0, sizeof(flag), c->stream));
   if (sflag) RS_HIP(c, hipMemsetAsync(c->static_scratch + kCtrlError, 0, sizeof(sflag), c->stream));
   flag |= sflag;
   if (flag & 2u)
     return fail(c, RS_ERR_KERNEL, "an output offset fell outside the array: the keys changed while the sort was running "
+                                  "(the stream that produces them was not waited for?); the result is not a sort of the input");
+  if (flag & 8u)
+    return fail(c, RS_ERR_KERNEL, "the group table of a hybrid sort names a range outside the array: the keys changed while the sort was running "
                                   "(the stream that produces them was not waited for?); the result is not a sort of the input");
   if (flag & 4u)
     return fail(c, RS_ERR_KERNEL, "a pass found its tile tickets already drawn (the control block was not clear when it started): nothing was moved");
@@ -769,9 +796,12 @@ int to_device(rs_ctx* c, void* d, const void* h, size_t bytes, int slot) {
     RS_HIP(c, c->mover.prepare(L));
     std::memcpy(L.pinned[slot], h, bytes);
     RS_HIP(c, hipMemcpyAsync(d, L.pinned[slot], bytes, hipMemcpyHostToDevice, c->stream));
+    RS_HIP(c, hipEventRecord(c->small_up, c->stream));      // lane 0's bounce buffer is busy until this copy has read it
+    c->small_up_pending = true;
     return RS_OK;
   }
   RS_HIP(c, hipStreamSynchronize(c->stream));
+  c->small_up_pending = false;
   RS_HIP(c, c->mover.move(c->device, static_cast<char*>(const_cast<void*>(h)), static_cast<char*>(d), bytes, true));
   return RS_OK;
 }
@@ -779,6 +809,13 @@ int to_device(rs_ctx* c, void* d, const void* h, size_t bytes, int slot) {
 // stream's kernels run (rs_sort_rows: the rows travel during the pair sort); a small one is queued on the stream.
 int to_device_beside_stream(rs_ctx* c, void* d, const void* h, size_t bytes, int slot) {
   if (!staged_transfers() || bytes < rst::kStagedMin) return to_device(c, d, h, bytes, slot);
+  // The lanes fill the same pinned buffers a small array of this call went through (to_device above), and the stream is
+  // NOT waited for here: wait for that one copy (rs_sort_rows: keys of less than 1 MiB, then rows of more -- the key
+  // DMA could otherwise still be reading the buffer while row bytes are written into it, and the sort would run on those).
+  if (c->small_up_pending) {
+    RS_HIP(c, hipEventSynchronize(c->small_up));
+    c->small_up_pending = false;
+  }
   RS_HIP(c, c->mover.move(c->device, static_cast<char*>(const_cast<void*>(h)), static_cast<char*>(d), bytes, true));
   return RS_OK;
 }
@@ -862,6 +899,7 @@ int rs_ctx_create(rs_ctx** out, int device) {
   }
   for (auto& e : c->ev)
     if (hipEventCreate(&e) != hipSuccess) { rs_ctx_destroy(c); return RS_ERR_HIP; }
+  if (hipEventCreateWithFlags(&c->small_up, hipEventDisableTiming) != hipSuccess) { c->small_up = nullptr; rs_ctx_destroy(c); return RS_ERR_HIP; }
   if (hipHostMalloc(reinterpret_cast<void**>(&c->pinned_flags), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
     c->pinned_flags = nullptr;
     rs_ctx_destroy(c);
@@ -929,6 +967,7 @@ int rs_ctx_destroy(rs_ctx* c) {
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  if (c->small_up) (void)hipEventDestroy(c->small_up);
   c->mover.release_all();
   if (c->pinned_flags) (void)hipHostFree(c->pinned_flags);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -35,7 +35,18 @@ struct GroupArgs {
   unsigned* big_list;          // groups too large for the LDS window: [0] = how many, [1..] = group numbers
   unsigned big_cap;            // room in big_list (entries)
   unsigned max_vec;            // groups whose window has more 16-byte vectors than this are left to the big-group kernel (<= BLOCK * MAXV)
+  unsigned n;                  // keys in the array: a group that does not lie inside it is reported (error word bit 3) and left alone
+  unsigned* error_flag;
 };
+
+// A group's range as the table gives it; false (and the error word set) when it cannot be a range of the array -- the table
+// is derived from counts taken earlier, and keys that changed since (a caller that did not wait for their producer) make it
+// inconsistent: nothing is read or written through such a range.
+__device__ __forceinline__ bool group_range_ok(unsigned start, unsigned end, unsigned n, unsigned* error_flag) {
+  if (start <= end && end <= n) return true;
+  if (threadIdx.x == 0) __hip_atomic_fetch_or(error_flag, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
 
 template <int BLOCK, int MAXV>
 struct GroupSmem {
@@ -289,6 +300,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
   __shared__ GroupSmem<BLOCK, MAXV> s;
   const unsigned g = blockIdx.x;
   const unsigned start = a.start[g], end = a.start[g + 1];
+  if (!group_range_ok(start, end, a.n, a.error_flag)) return;
   if (end <= start + 1u) {                      // empty, or one key: in place already -- but the store applies the transform
     if (end == start || !(a.fmask_out | a.smask_out)) return;
   }
@@ -317,6 +329,35 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
 }
 
 // ------------------------------------------------------------------------------------------------
+// Groups of wider keys, or of more low bits
+// ------------------------------------------------------------------------------------------------
+// The same finish for keys whose low part does not fit 16 bits -- 8-byte keys after the two sweeps on their top digits
+// (48 low bits), or 4-byte keys grouped by one top digit only (24 low bits; mid-size sorts): one workgroup takes a group's
+// whole keys into LDS and runs the single-workgroup sort's loop over the low bits (tile_sort_body, rsort_kernels.hpp:
+// stable LDS passes of 8 bits, digits that are the same for the whole group skipped), one read and one write of the keys
+// whatever the number of passes.  8-byte keys at N = 2^30: 8 + 2 * 16 + 16 = 56 bytes per key instead of the canonical 136.
+template <typename K, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
+  __shared__ TileSortSmem<K, NoVal, BLOCK, ITEMS> s;
+  const unsigned g = blockIdx.x;
+  const unsigned start = a.start[g], end = a.start[g + 1];
+  if (!group_range_ok(start, end, a.n, a.error_flag)) return;
+  if (end <= start + 1u) {
+    if (end == start || !(a.fmask_out | a.smask_out)) return;
+  }
+  const unsigned len = end - start;
+  if (len > a.max_vec) {          // (here max_vec counts keys) workgroup-uniform: left to group_big_kernel
+    if (threadIdx.x == 0) {
+      const unsigned slot = atomicAdd(&a.big_list[0], 1u);
+      if (slot < a.big_cap) a.big_list[1 + slot] = g;
+    }
+    return;
+  }
+  tile_sort_body<K, NoVal, BLOCK, ITEMS>(s, static_cast<K*>(a.keys) + start, nullptr, len, static_cast<K>(0), static_cast<K>(0),
+                                         static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), 0, a.low_bits);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Where the groups start
 // ------------------------------------------------------------------------------------------------
 // After the sweep on the upper top digit (hi) of an array that the sweep before it had ordered by the lower top digit (lo),
@@ -329,7 +370,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
 // looks at), one thread per value of the upper digit; at most one tile of keys is read per workgroup.
 struct TableArgs {
   const uint32_t* desc;                  // [tiles][256] 4-byte descriptors left by the sweep on the upper digit
-  const uint32_t* keys_in;               // that sweep's input
+  const void* keys_in;                   // that sweep's input (keys of K bytes, transformed already)
   const unsigned long long* gbase_lo;    // [256] where each value of the lower digit starts in keys_in
   const unsigned long long* gbase_hi;    // [256] where each value of the upper digit starts in the sweep's output
   const unsigned long long* chain_cnt;   // chain mode: the upper digit's counts over each chain's input range, row c at c * chain_cnt_stride
@@ -341,6 +382,7 @@ struct TableArgs {
   unsigned* start;                       // out: [65537], group g = hi * 256 + lo; start[65536] = n
 };
 
+template <typename K>
 __global__ __launch_bounds__(kRadix) void group_table_kernel(TableArgs a) {
   __shared__ unsigned part[kRadix];
   const unsigned lo = blockIdx.x, hi = threadIdx.x;
@@ -353,8 +395,8 @@ __global__ __launch_bounds__(kRadix) void group_table_kernel(TableArgs a) {
   } else {
     const unsigned pos = static_cast<unsigned>(pos64);
     const unsigned t = pos / a.tile, r = pos - t * a.tile;
-    const uint32_t* kin = a.keys_in + static_cast<size_t>(t) * a.tile;
-    for (unsigned i = hi; i < r; i += kRadix) atomicAdd(&part[(kin[i] >> a.shift_hi) & 0xFFu], 1u);
+    const K* kin = static_cast<const K*>(a.keys_in) + static_cast<size_t>(t) * a.tile;
+    for (unsigned i = hi; i < r; i += kRadix) atomicAdd(&part[static_cast<unsigned>(kin[i] >> a.shift_hi) & 0xFFu], 1u);
     __syncthreads();
     const unsigned chain = a.chain_tiles ? t / a.chain_tiles : 0u;
     const unsigned first = chain * a.chain_tiles;
@@ -383,6 +425,8 @@ struct BigArgs {
   unsigned big_cap;
   int low_bits;
   uint64_t fmask_out, smask_out;
+  unsigned n;
+  unsigned* error_flag;
 };
 
 template <typename K, int BLOCK, int ITEMS>
@@ -400,6 +444,7 @@ __global__ __launch_bounds__(BLOCK) void group_big_kernel(BigArgs a) {
   };
   for (unsigned e = blockIdx.x; e < listed; e += gridDim.x) {
     const unsigned g = a.big_list[1 + e];
+    if (g >= 65536u || !group_range_ok(a.start[g], a.start[g + 1], a.n, a.error_flag)) continue;      // (workgroup-uniform)
     const unsigned gs = a.start[g], len = a.start[g + 1] - gs;
     K* src = static_cast<K*>(a.keys) + gs;
     K* dst = static_cast<K*>(a.alt) + gs;

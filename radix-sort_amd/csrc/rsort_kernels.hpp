@@ -1358,35 +1358,43 @@ struct SmallArgs {
 };
 
 template <typename K, typename V, int BLOCK, int ITEMS>
-__global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
+struct TileSortSmem {
+  static constexpr int WAVES = BLOCK / kWave;
+  static constexpr int TILE = BLOCK * ITEMS;
+  static constexpr bool HAS_VAL = !__is_same(V, NoVal);
+  alignas(16) K stage_k[TILE];
+  alignas(16) V stage_v[HAS_VAL ? TILE : 1];
+  alignas(16) unsigned short whist[WAVES][kRadix];   // (updated two cells at a time through 32-bit LDS atomics: word-aligned, whatever precedes it)
+  unsigned wave_total[kRadix / kWave];
+};
+
+// The whole sort of at most BLOCK * ITEMS keys (and payload) by one workgroup, in place at gk / gv: every pass in registers
+// and LDS.  fm_in / sm_in: transform applied to the keys as they are read (zero when they are transformed already);
+// fm_out / sm_out: inverse transform applied as they are stored.  Used by small_sort_kernel (one array) and by
+// group_sort_wide_kernel (rsort_groups.hpp: one group of a larger array per call).  Ends with every thread past its last
+// LDS access of the call only after a barrier of its own, so calls can follow each other in one kernel.
+template <typename K, typename V, int BLOCK, int ITEMS>
+__device__ __forceinline__ void tile_sort_body(TileSortSmem<K, V, BLOCK, ITEMS>& s, K* gk, V* gv, unsigned n, K fm_in, K sm_in,
+                                               K fm_out, K sm_out, int begin_bit, int end_bit) {
   constexpr int WAVES = BLOCK / kWave;
   constexpr int TILE = BLOCK * ITEMS;
   constexpr bool HAS_VAL = !__is_same(V, NoVal);
   static_assert(TILE < 65536 && BLOCK >= kRadix, "16-bit positions; one thread per digit");
-  __shared__ K stage_k[TILE];
-  __shared__ V stage_v[HAS_VAL ? TILE : 1];
-  __shared__ unsigned short whist[WAVES][kRadix];
-  __shared__ unsigned wave_total[kRadix / kWave];
-
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const unsigned seg = wave * (kWave * ITEMS) + lane;
-  const unsigned n = a.n;
-  K* gk = static_cast<K*>(a.keys);
-  V* gv = static_cast<V*>(a.vals);
-  const K fm = static_cast<K>(a.fmask), sm = static_cast<K>(a.smask);
 
   K key[ITEMS];
   V val[HAS_VAL ? ITEMS : 1];
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const unsigned idx = seg + i * kWave;
-    key[i] = idx < n ? xf_forward(gk[idx], fm, sm) : static_cast<K>(0);
+    key[i] = idx < n ? xf_forward(gk[idx], fm_in, sm_in) : static_cast<K>(0);
     if constexpr (HAS_VAL) { if (idx < n) val[i] = gv[idx]; }
   }
 
-  unsigned* wwords = reinterpret_cast<unsigned*>(whist[wave]);
-  for (int shift = a.begin_bit; shift < a.end_bit; shift += kRadixBits) {
-    const int bits = a.end_bit - shift < kRadixBits ? a.end_bit - shift : kRadixBits;
+  unsigned* wwords = reinterpret_cast<unsigned*>(s.whist[wave]);
+  for (int shift = begin_bit; shift < end_bit; shift += kRadixBits) {
+    const int bits = end_bit - shift < kRadixBits ? end_bit - shift : kRadixBits;
 #pragma unroll
     for (int i = 0; i < kRadix / 2 / kWave; ++i) wwords[i * kWave + lane] = 0;
     // rank inside the wave (see onesweep_kernel: lane order inside one returning LDS add, round order inside the wave)
@@ -1403,7 +1411,7 @@ __global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
     unsigned my_count = 0, inc = 0;
     if (tid < kRadix) {
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) my_count += whist[w][tid];
+      for (int w = 0; w < WAVES; ++w) my_count += s.whist[w][tid];
       unsigned v = my_count;
 #pragma unroll
       for (int off = 1; off < kWave; off <<= 1) {
@@ -1411,17 +1419,17 @@ __global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
         if (lane >= static_cast<unsigned>(off)) v += u;
       }
       inc = v;
-      if (lane == kWave - 1) wave_total[wave] = v;
+      if (lane == kWave - 1) s.wave_total[wave] = v;
     }
     if (__syncthreads_or(tid < kRadix && my_count == n)) continue;     // workgroup-uniform
     if (tid < kRadix) {
       unsigned before = 0;
-      for (unsigned w = 0; w < wave; ++w) before += wave_total[w];
+      for (unsigned w = 0; w < wave; ++w) before += s.wave_total[w];
       unsigned sum = before + inc - my_count;       // start of the digit's run, then + the waves before each wave
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) {
-        unsigned c = whist[w][tid];
-        whist[w][tid] = static_cast<unsigned short>(sum);
+        unsigned c = s.whist[w][tid];
+        s.whist[w][tid] = static_cast<unsigned short>(sum);
         sum += c;
       }
     }
@@ -1429,9 +1437,9 @@ __global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       if (seg + i * kWave < n) {
-        const unsigned pos = whist[wave][digit_at(key[i], shift, bits)] + rank[i];
-        stage_k[pos] = key[i];
-        if constexpr (HAS_VAL) stage_v[pos] = val[i];
+        const unsigned pos = s.whist[wave][digit_at(key[i], shift, bits)] + rank[i];
+        s.stage_k[pos] = key[i];
+        if constexpr (HAS_VAL) s.stage_v[pos] = val[i];
       }
     }
     __syncthreads();
@@ -1439,8 +1447,8 @@ __global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
     for (int i = 0; i < ITEMS; ++i) {
       const unsigned idx = seg + i * kWave;
       if (idx < n) {
-        key[i] = stage_k[idx];
-        if constexpr (HAS_VAL) val[i] = stage_v[idx];
+        key[i] = s.stage_k[idx];
+        if constexpr (HAS_VAL) val[i] = s.stage_v[idx];
       }
     }
     // no barrier: the next pass writes the staging area only behind its own two barriers, and each wave zeroes and
@@ -1450,10 +1458,17 @@ __global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
   for (int i = 0; i < ITEMS; ++i) {
     const unsigned idx = seg + i * kWave;
     if (idx < n) {
-      gk[idx] = xf_inverse(key[i], fm, sm);
+      gk[idx] = xf_inverse(key[i], fm_out, sm_out);
       if constexpr (HAS_VAL) gv[idx] = val[i];
     }
   }
+}
+
+template <typename K, typename V, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
+  __shared__ TileSortSmem<K, V, BLOCK, ITEMS> s;
+  const K fm = static_cast<K>(a.fmask), sm = static_cast<K>(a.smask);
+  tile_sort_body<K, V, BLOCK, ITEMS>(s, static_cast<K*>(a.keys), static_cast<V*>(a.vals), a.n, fm, sm, fm, sm, a.begin_bit, a.end_bit);
 }
 
 }  // namespace rsk

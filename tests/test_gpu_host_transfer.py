@@ -79,3 +79,27 @@ def test_ordered_input_is_returned_without_a_download():
         mixed = asc.copy(); mixed[n // 2] = 0                       # one descent: a real sort, result fetched
         assert eng.sort_keys_host(mixed).tobytes() == np.sort(mixed).tobytes()
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precheck", [True, False])
+def test_rows_small_key_column_large_rows(precheck):
+    """rs_sort_rows with a key column that travels through the small-array bounce buffer (< 1 MiB) and rows that travel
+    through the transfer lanes (>= 1 MiB) WHILE the pair sort runs: the lanes reuse the bounce buffer, so the key copy must
+    have read it first (one-workgroup sorts and sorts without the pre-check never wait for the stream in between)."""
+    import ctypes as C
+    eng = rs.Engine(0)
+    eng.set_precheck(precheck)
+    eng.set_host_threads(4)
+    rng = np.random.default_rng(31)
+    for n, row_bytes in [(8192, 256), (16384, 64), (5000, 256), (200_000, 16)]:
+        for rep in range(3):
+            keys = rng.integers(0, 50, n, dtype=np.int32)                       # many ties: stability shows in the rows
+            rows = rng.integers(0, 2**32, (n, row_bytes // 4), dtype=np.uint32)
+            rows[:, 0] = np.arange(n, dtype=np.uint32)                          # the row's original position
+            got = rows.copy()
+            rc = eng.lib.rs_sort_rows(eng.h, got.ctypes.data_as(C.c_void_p), n, row_bytes, keys.ctypes.data_as(C.c_void_p), 4, 1)
+            assert rc == 0, eng.lib.rs_last_error(eng.h)
+            order = np.argsort(keys, kind="stable")
+            assert got.tobytes() == rows[order].tobytes(), (n, row_bytes, rep)
+    eng.close()

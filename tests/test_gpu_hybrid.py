@@ -13,7 +13,7 @@ from radix_sort_amd import shapes
 
 pytestmark = pytest.mark.gpu
 
-HYBRID_SIZES = [4_300_001, 5_000_000, (1 << 23) + 7]
+HYBRID_SIZES = [4_300_001, 5_000_000, (1 << 23) + 7]     # (more than 256 tiles of either geometry: mid-size sorts never take the hybrid form)
 
 
 def _sort_on_device(engine, v, xf, offset=0):
@@ -30,7 +30,7 @@ def _sort_on_device(engine, v, xf, offset=0):
     return view.cpu().numpy().view(v.dtype), took_hybrid
 
 
-@pytest.mark.parametrize("name", ["u32", "i32", "f32"])
+@pytest.mark.parametrize("name", ["u32", "i32", "f32", "u64", "i64", "f64"])
 @pytest.mark.parametrize("shape", shapes.SHAPES)
 def test_hybrid_matches_oracle(engine, oracle, name, shape):
     dt, kb, xf = shapes.KEY_TYPES[name]
@@ -70,7 +70,7 @@ def test_hybrid_unaligned_and_big_groups(engine, oracle):
                 assert hybrid and got.tobytes() == want.tobytes(), (what, offset)
         for limit in (1, 8, 40):                      # groups of more than 4 * limit keys: big-group kernel
             engine.lib.rs_debug_set_group_limit(engine.h, limit)
-            for name in ("u32", "f32"):
+            for name in ("u32", "f32", "u64", "f64"):
                 dt, kb, xf = shapes.KEY_TYPES[name]
                 v = shapes.generate(name, n, "randomized", seed=limit)
                 got, hybrid = _sort_on_device(engine, v, xf, 2)
@@ -92,14 +92,14 @@ import radix_sort_amd as rs
 from radix_sort_amd import shapes
 from cpu_checkers import load_oracle
 orc = load_oracle(); eng = rs.Engine(0); eng.set_precheck(False); eng.set_hybrid(1)
-for name in ("u32", "i32", "f32"):
+for name in ("u32", "i32", "f32", "u64", "f64"):
     dt, kb, xf = shapes.KEY_TYPES[name]
     for shape in shapes.SHAPES:
         for n in (4_300_001, (1 << 23) + 13):
             v = shapes.generate(name, n, shape)
-            t = torch.from_numpy(v.view(np.uint32).copy()).cuda()
+            t = torch.from_numpy(v.view(np.uint8).copy()).cuda()
             torch.cuda.synchronize()
-            eng.sort_keys_ptr(t.data_ptr(), n, 4, xf); eng.synchronize()
+            eng.sort_keys_ptr(t.data_ptr(), n, kb, xf); eng.synchronize()
             assert eng.lib.rs_debug_last_hybrid(eng.h) == 1
             assert t.cpu().numpy().view(v.dtype).tobytes() == orc.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
 print("CHAIN HYBRID OK")
@@ -119,9 +119,11 @@ def test_hybrid_at_full_size():
     eng.set_precheck(False)
     try:
         n = 1 << 30
-        for shape in ("randomized", "ramp", "duplicates"):
+        for shape in ("randomized", "ramp", "duplicates", "randomized 8-byte"):
             g = torch.Generator(device="cuda"); g.manual_seed(11)
-            if shape == "randomized":
+            if shape == "randomized 8-byte":
+                keys = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device="cuda", generator=g)
+            elif shape == "randomized":
                 keys = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, device="cuda", generator=g)
             elif shape == "ramp":
                 keys = (torch.arange(n, dtype=torch.int64, device="cuda") * 4 - 2**31).to(torch.int32)
@@ -130,7 +132,7 @@ def test_hybrid_at_full_size():
             else:
                 vals = torch.randint(-2**31, 2**31 - 1, (256,), dtype=torch.int32, device="cuda", generator=g)
                 keys = vals[torch.randint(0, 256, (n,), device="cuda", generator=g)]
-            want_sum = int(keys.sum(dtype=torch.int64).item())
+            want_sum = int(keys.sum(dtype=torch.int64).item())          # (wraps for 8-byte keys, the same way before and after)
             torch.cuda.synchronize()
             eng.sort_keys_(keys, 1)
             eng.synchronize()

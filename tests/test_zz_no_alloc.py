@@ -37,6 +37,15 @@ def test_noalloc_matches_allocating_entry_point_twice(engine, name):
         assert got.tobytes() == want.tobytes(), (name, host.size)
 
 
+def test_noalloc_at_its_size_limit(engine):
+    """8-byte keys at n = 2^25, the largest input the static workspace serves: every descriptor row it holds is in use."""
+    import torch
+    host = shapes.generate("u64", 1 << 25, "randomized", seed=9)
+    want, got = _both(engine, torch, host, 0)
+    assert got.tobytes() == want.tobytes()
+    assert bool(np.all(got[:-1] <= got[1:])) and int(got.sum(dtype=np.uint64)) == int(host.sum(dtype=np.uint64))
+
+
 def test_noalloc_small_sizes_and_ordered_input(engine):
     import torch
     dt, kb, xf = shapes.KEY_TYPES["i32"]

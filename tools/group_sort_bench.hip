@@ -37,7 +37,7 @@ __global__ void check_kernel(const unsigned* keys, size_t n, unsigned long long*
 template <int BLOCK, int MAXV, int MINB>
 static void run(const char* name, unsigned* keys, unsigned* pristine, const unsigned* d_start, unsigned groups, size_t n, unsigned* big, unsigned long long* chk) {
   rsk::GroupArgs a{};
-  a.keys = keys; a.start = d_start; a.groups = groups; a.low_bits = 16; a.big_list = big; a.big_cap = 65536; a.max_vec = BLOCK * MAXV;
+  a.keys = keys; a.start = d_start; a.groups = groups; a.low_bits = 16; a.big_list = big; a.big_cap = 65536; a.max_vec = BLOCK * MAXV; a.n = static_cast<unsigned>(n); a.error_flag = big + 65536;
   unsigned long long want[2], got[2];
   CK(hipMemset(chk, 0, 16));
   check_kernel<<<4096, 256>>>(pristine, n, chk);
