@@ -85,8 +85,7 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
 constexpr size_t kHybridMinKeys = 120000000;   // hybrid form of 4-byte key sorts from here on (measured: 2^27 keys 1.19 against 1.34 ms, 2^26 keys 0.77 against 0.67 -- below, the fixed cost of 65536 workgroups outweighs the two sweeps saved)
-constexpr size_t kHybridMinKeysWide = 400000000;   // the same for 8-byte keys (2^29 keys: 12.8 against 15.0 ms; 2^28: 9.7 against 7.6 -- its 65536 workgroups of 1024 threads
-                                                  // each run six LDS passes whatever the group's size: 5 ms of fixed cost)
+constexpr size_t kHybridMinKeysWide = 250000000;   // the same for 8-byte keys (2^28 keys: 7.2 against 7.6 ms; 2^27: 4.6 against 4.0 -- its 65536 workgroups run up to six LDS passes each)
 constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) neither pass skipping nor the order pre-check is worth a host synchronisation
 
 // Hybrid sort of 4-byte keys (rsort_groups.hpp): two sweeps on the top digits, then every group of equal top 16 bits is
@@ -98,6 +97,9 @@ constexpr size_t kGroupCap = size_t(kGroupBlock) * kGroupMaxVec * 4 - 3;   // ke
 constexpr int kWideGroupBlock = 1024;
 constexpr int kWideGroupItems = 17;
 constexpr size_t kWideGroupCap = size_t(kWideGroupBlock) * kWideGroupItems;
+// mid-size sorts of 4-byte keys: groups of equal top byte, whole keys in LDS (rsk::group_sort_mid_kernel), 1024 x 20 keys = 80 KB
+constexpr int kMidGroupBlock = 1024;
+constexpr int kMidGroupItems = 20;
 constexpr unsigned kGroupCount = 65536;
 constexpr size_t kGroupsBytes = (size_t(kGroupCount) + 1 + kGroupCount + 1) * sizeof(unsigned);   // start table + list of oversize groups
 
@@ -130,7 +132,7 @@ struct rs_ctx {
   int hybrid_mode = -1;          // hybrid form of 4-byte key sorts: -1 chosen per sort, 0 never, 1 whenever the shape allows (rs_ctx_set_hybrid; RSORT_HYBRID at creation)
   unsigned group_max_vec = 0;    // test hook: groups of more vectors than this go to the big-group kernel (0 = what the LDS window holds)
   bool last_hybrid = false;      // the last sort_device took the hybrid form
-  hipEvent_t ev[kMaxPasses + 2] = {};
+  hipEvent_t ev[kMaxPasses + 4] = {};
   hipEvent_t small_up = nullptr;     // after the last small host-to-device copy through lane 0's bounce buffer (to_device)
   bool small_up_pending = false;
   int ev_count = 0;
@@ -662,6 +664,15 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     live[0] = top_lo; live[1] = top_hi; n_live = 2;
   }
 
+  // Mid-size keys-only sorts of whole 4- and 8-byte keys: the short form -- ONE sweep on the top digit, then one launch in
+  // which workgroup g finishes the keys of top digit g in LDS (rsk::group_sort_mid_kernel) -- whenever every group fits its
+  // window.  Whether they do is only known on the device and a mid-size sort does not wait for it, so the kernels of both
+  // forms are queued and decide for themselves (rsk::SweepArgs::mid_counts): a sort that takes the short form pays K - 1
+  // launches that leave at once; one that cannot (keys that share their top byte: small integers) runs the LSD loop as before.
+  const bool mid_short = mid && in_tile_scan && !ws && c->hybrid_mode != 0 && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) &&
+                         begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic && n_live == key_bytes;
+  const unsigned mid_cap = key_bytes == 4 ? kMidGroupBlock * kMidGroupItems : static_cast<unsigned>(kWideGroupCap);
+
   void* kin = keys; void* kout = alt_keys;
   void* vin = vals; void* vout = alt_vals;
   if (chain && !sweep_chain && sweep_tiles * 256 * (wide ? size_t(8) : size_t(4)) > desc_clear)
@@ -694,11 +705,28 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
         a.next_bits = std::min(rsk::kRadixBits, end_bit - a.next_shift);
       }
     }
+    if (mid_short) {
+      a.mid_counts = ghist + top_hi * rsk::kRadix;
+      a.mid_cap = mid_cap;
+      a.mid_role = p == top_hi ? 2 : 1;
+      a.mid_keys_in = keys; a.mid_keys_out = alt_keys;            // the short form's only sweep: caller's keys -> alternate buffer
+      a.mid_fmask_in = fmask; a.mid_smask_in = smask;
+    }
     launch_sweep_k(a, launch);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     std::swap(kin, kout);
     std::swap(vin, vout);
     last_sweep = a;
+  }
+  if (mid_short) {
+    rsk::MidArgs m{};
+    m.keys_in = alt_keys; m.keys_out = keys; m.counts = ghist + top_hi * rsk::kRadix; m.cap = mid_cap;
+    m.low_bits = top_hi * rsk::kRadixBits; m.fmask_out = fmask; m.smask_out = smask;
+    if (key_bytes == 4)
+      hipLaunchKernelGGL((rsk::group_sort_mid_kernel<uint32_t, kMidGroupBlock, kMidGroupItems>), dim3(rsk::kRadix), dim3(kMidGroupBlock), 0, s, m);
+    else
+      hipLaunchKernelGGL((rsk::group_sort_mid_kernel<uint64_t, kWideGroupBlock, kWideGroupItems>), dim3(rsk::kRadix), dim3(kWideGroupBlock), 0, s, m);
+    if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
   }
   if (hybrid) {
     // (two sweeps: the grouped keys are back in `keys`, the second sweep's input is intact in alt_keys)

@@ -336,6 +336,23 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
 // whole keys into LDS and runs the single-workgroup sort's loop over the low bits (tile_sort_body, rsort_kernels.hpp:
 // stable LDS passes of 8 bits, digits that are the same for the whole group skipped), one read and one write of the keys
 // whatever the number of passes.  8-byte keys at N = 2^30: 8 + 2 * 16 + 16 = 56 bytes per key instead of the canonical 136.
+// tile_sort_body for a group of len keys, instantiated for the smallest of 1, 2, 4, 8, 12, 16, ITEMS keys per thread that holds it
+template <typename K, int BLOCK, int ITEMS, typename Smem>
+__device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, unsigned len, K fmo, K smo, int low_bits) {
+  const unsigned per = (len + BLOCK - 1) / BLOCK;        // (workgroup-uniform)
+  auto run = [&](auto it_tag) {
+    constexpr int IT = decltype(it_tag)::value < ITEMS ? decltype(it_tag)::value : ITEMS;
+    tile_sort_body<K, NoVal, BLOCK, IT>(s, gin, gout, static_cast<NoVal*>(nullptr), len, static_cast<K>(0), static_cast<K>(0), fmo, smo, 0, low_bits);
+  };
+  if (per <= 1) run(std::integral_constant<int, 1>{});
+  else if (per <= 2) run(std::integral_constant<int, 2>{});
+  else if (per <= 4) run(std::integral_constant<int, 4>{});
+  else if (per <= 8) run(std::integral_constant<int, 8>{});
+  else if (per <= 12) run(std::integral_constant<int, 12>{});
+  else if (per <= 16) run(std::integral_constant<int, 16>{});
+  else run(std::integral_constant<int, ITEMS>{});
+}
+
 template <typename K, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
   __shared__ TileSortSmem<K, NoVal, BLOCK, ITEMS> s;
@@ -353,8 +370,42 @@ __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
     }
     return;
   }
-  tile_sort_body<K, NoVal, BLOCK, ITEMS>(s, static_cast<K*>(a.keys) + start, nullptr, len, static_cast<K>(0), static_cast<K>(0),
-                                         static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), 0, a.low_bits);
+  group_tile_sort<K, BLOCK, ITEMS>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, len,
+                                   static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), a.low_bits);
+}
+
+// Mid-size sorts (at most 256 tiles; SweepArgs::mid_counts has the protocol): after ONE sweep on the top digit, workgroup g
+// sorts the keys whose top digit is g on their remaining bits, from the sweep's output buffer into the caller's.  No table
+// kernel: the 256 counts ARE the group sizes, and every workgroup sums the ones before its own.  Leaves at once when some
+// group does not fit (then the LSD passes queued beside it are doing the sort).
+struct MidArgs {
+  const void* keys_in;                   // the top-digit sweep's output
+  void* keys_out;                        // the caller's array
+  const unsigned long long* counts;      // the top digit's 256 counts
+  unsigned cap;                          // <= BLOCK * ITEMS
+  int low_bits;
+  uint64_t fmask_out, smask_out;
+};
+
+template <typename K, int BLOCK, int ITEMS>
+__global__ __launch_bounds__(BLOCK) void group_sort_mid_kernel(MidArgs a) {
+  __shared__ TileSortSmem<K, NoVal, BLOCK, ITEMS> s;
+  __shared__ unsigned long long part[kRadix / kWave];
+  const unsigned g = blockIdx.x, tid = threadIdx.x;
+  const unsigned long long c = tid < kRadix ? a.counts[tid] : 0ull;
+  if (__syncthreads_or(c > a.cap)) return;              // (kernel-uniform)
+  if (tid < kRadix) {
+    unsigned long long v = tid < g ? c : 0ull;          // keys of the groups before this one
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    if ((tid & (kWave - 1)) == 0) part[tid / kWave] = v;
+  }
+  __syncthreads();
+  const unsigned start = static_cast<unsigned>(part[0] + part[1] + part[2] + part[3]);
+  const unsigned len = static_cast<unsigned>(a.counts[g]);
+  if (len == 0) return;
+  group_tile_sort<K, BLOCK, ITEMS>(s, static_cast<const K*>(a.keys_in) + start, static_cast<K*>(a.keys_out) + start, len,
+                                   static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), a.low_bits);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -450,6 +450,18 @@ struct SweepArgs {
                                          // pass' output (accumulated here); null in the last pass
   int next_shift, next_bits;             // the next launched pass' digit
   unsigned chunk_shift, chunk_mul;       // chain of output position o = (mul_u24(o >> chunk_shift, chunk_mul)) >> 16
+  // Mid-size keys-only sorts (rsort_api.hip): the host queues every kernel of BOTH forms without looking at a count, and
+  // each kernel decides for itself, from the top digit's 256 counts, which form is running -- the same answer in all of
+  // them.  When every group of equal top digit fits the group kernel's LDS window (rsk::group_sort_mid_kernel), the sort is
+  // one sweep on the top digit plus that kernel; otherwise it is the LSD loop as before.
+  const unsigned long long* mid_counts;  // non-null: this launch has a role in such a sort; the top digit's counts
+  unsigned mid_cap;                      // the window: groups of at most this many keys
+  int mid_role;                          // 1 = a lower digit's pass: leaves at once when the groups fit;
+                                         // 2 = the top digit's pass: last LSD pass as its other arguments say when they do not fit, FIRST
+                                         //     pass of the short form when they do, with the operands below and no inverse transform
+  const void* mid_keys_in;
+  void* mid_keys_out;
+  uint64_t mid_fmask_in, mid_smask_in;
 };
 
 // Lanes of the wave whose digit DIFFERS from this lane's, as two 32-bit halves: per bit, the
@@ -691,7 +703,19 @@ struct ChainSmem {
 struct NoChainSmem {};
 
 template <typename K, typename V, typename D, int BLOCK, int ITEMS, int LOOKBACK = 8, int MIN_BLOCKS = 1, bool RANK_BY_LDS_ATOMIC = true, bool CHAIN = false, bool COUNT = false>
-__global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesweep_kernel(SweepArgs a) {
+__global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesweep_kernel(SweepArgs a_in) {
+  SweepArgs a = a_in;
+  if constexpr (!CHAIN && sizeof(D) == 4) {
+    if (a.mid_counts != nullptr) {               // (kernel-uniform) see SweepArgs
+      const bool over = threadIdx.x < kRadix && a.mid_counts[threadIdx.x] > a.mid_cap;
+      if (!__syncthreads_or(over)) {             // every group fits: the short form runs
+        if (a.mid_role == 1) return;
+        a.keys_in = a.mid_keys_in; a.keys_out = a.mid_keys_out;
+        a.fmask_in = a.mid_fmask_in; a.smask_in = a.mid_smask_in;
+        a.fmask_out = 0; a.smask_out = 0;
+      }
+    }
+  }
 #ifdef RS_NO_WIDE_CELLS
   constexpr bool WIDE_CELLS = false;
 #else
@@ -1368,16 +1392,20 @@ struct TileSortSmem {
   unsigned wave_total[kRadix / kWave];
 };
 
-// The whole sort of at most BLOCK * ITEMS keys (and payload) by one workgroup, in place at gk / gv: every pass in registers
-// and LDS.  fm_in / sm_in: transform applied to the keys as they are read (zero when they are transformed already);
+// The whole sort of at most BLOCK * ITEMS keys (and payload) by one workgroup, keys read at gin and stored at gk (the same
+// array, or two of one size), payload in place at gv: every pass in registers and LDS.  fm_in / sm_in: transform applied to the keys as they are read (zero when they are transformed already);
 // fm_out / sm_out: inverse transform applied as they are stored.  Used by small_sort_kernel (one array) and by
 // group_sort_wide_kernel (rsort_groups.hpp: one group of a larger array per call).  Ends with every thread past its last
 // LDS access of the call only after a barrier of its own, so calls can follow each other in one kernel.
-template <typename K, typename V, int BLOCK, int ITEMS>
-__device__ __forceinline__ void tile_sort_body(TileSortSmem<K, V, BLOCK, ITEMS>& s, K* gk, V* gv, unsigned n, K fm_in, K sm_in,
+// ITEMS = keys per thread of THIS call: at most what the shared-memory block was sized for (a kernel that sorts groups of
+// different sizes instantiates the body for several and picks the smallest that holds the group: every phase is a loop
+// over ITEMS rounds whether they hold keys or not).
+template <typename K, typename V, int BLOCK, int ITEMS, typename Smem>
+__device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* gv, unsigned n, K fm_in, K sm_in,
                                                K fm_out, K sm_out, int begin_bit, int end_bit) {
   constexpr int WAVES = BLOCK / kWave;
   constexpr int TILE = BLOCK * ITEMS;
+  static_assert(TILE <= Smem::TILE && BLOCK == Smem::WAVES * kWave, "the staging area holds the call's keys");
   constexpr bool HAS_VAL = !__is_same(V, NoVal);
   static_assert(TILE < 65536 && BLOCK >= kRadix, "16-bit positions; one thread per digit");
   const unsigned tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -1388,7 +1416,7 @@ __device__ __forceinline__ void tile_sort_body(TileSortSmem<K, V, BLOCK, ITEMS>&
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const unsigned idx = seg + i * kWave;
-    key[i] = idx < n ? xf_forward(gk[idx], fm_in, sm_in) : static_cast<K>(0);
+    key[i] = idx < n ? xf_forward(gin[idx], fm_in, sm_in) : static_cast<K>(0);
     if constexpr (HAS_VAL) { if (idx < n) val[i] = gv[idx]; }
   }
 
@@ -1468,7 +1496,7 @@ template <typename K, typename V, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void small_sort_kernel(SmallArgs a) {
   __shared__ TileSortSmem<K, V, BLOCK, ITEMS> s;
   const K fm = static_cast<K>(a.fmask), sm = static_cast<K>(a.smask);
-  tile_sort_body<K, V, BLOCK, ITEMS>(s, static_cast<K*>(a.keys), static_cast<V*>(a.vals), a.n, fm, sm, fm, sm, a.begin_bit, a.end_bit);
+  tile_sort_body<K, V, BLOCK, ITEMS>(s, static_cast<const K*>(a.keys), static_cast<K*>(a.keys), static_cast<V*>(a.vals), a.n, fm, sm, fm, sm, a.begin_bit, a.end_bit);
 }
 
 }  // namespace rsk

@@ -181,6 +181,22 @@ def test_mid_size_sorts_between_other_calls(engine, oracle):
         assert (got == v[np.argsort(v >> 24, kind="stable")]).all()
         mid("u32", 150_000, seed=6)
         mid("f32", 1_000_000, "nearly_sorted")
+        # the short form of mid-size sorts (one sweep on the top byte, groups of equal top byte finished in LDS) and the
+        # inputs that must NOT take it -- decided on the device, with the kernels of both forms queued: keys that share their
+        # top byte (one group of everything), few top bytes (groups beyond the window), a window's worth exactly, every shape
+        for name in ("u32", "i32", "f32", "u64", "i64", "f64"):
+            for shape in shapes.SHAPES:
+                mid(name, 777_777, shape, seed=3)
+        for n in (20_000, 300_000, 2_000_000):
+            dt = np.uint32
+            small = rng.integers(0, 1 << 20, n, dtype=np.uint64).astype(dt)             # top byte constant
+            four = (rng.integers(0, 4, n, dtype=np.uint64).astype(dt) << dt(30)) | rng.integers(0, 1 << 24, n, dtype=np.uint64).astype(dt)
+            skew = np.where(rng.random(n) < 0.7, dt(0x7F000000), dt(0)) | rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(dt) >> dt(4)
+            for v in (small, four, skew, small.astype(np.uint64) << np.uint64(20)):
+                t = torch.from_numpy(v.view(np.uint8).copy()).cuda()
+                engine.sort_keys_ptr(t.data_ptr(), n, v.itemsize, 0)
+                engine.synchronize()
+                assert t.cpu().numpy().tobytes() == np.sort(v).tobytes(), (n, v.dtype)
         # host-buffer calls: pre-check read-back before the histogram, pairs through the same control block
         engine.set_precheck(True)
         a = shapes.generate("u32", 120_000, "sorted", seed=1)
