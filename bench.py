@@ -164,6 +164,7 @@ def bench_single(args):
                 dominant = {"bound": "hbm", "kernel": f"onesweep_kernel<{name}> (all launches of one sort: the counting and the last-pass instantiation of the chain-mode sweep)", "achieved": achieved,
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": load_traffic(name),
+                            "traffic_source": "profiles/traffic.json (" + str(load_traffic(name, True)[1]) + "): rocprofv3 --pmc passes of the committed profile set, not collected in this run",
                             "bytes_per_launch": n * 2 * kb, "avg_launch_ms": avg_pass * 1e3,
                             "whole_sort_frac": row["hbm_frac"] if row["hbm_frac"] else row["full_sort"]["hbm_frac"],
                             "whole_sort_bytes_moved_per_key": row.get("bytes_moved_per_key") or row["full_sort"].get("bytes_moved_per_key")}
@@ -301,14 +302,16 @@ def bench_composite(n):
     return {"error": "no result line", "output": out[-400:]}
 
 
-def load_traffic(name):
-    """HBM bytes per onesweep launch from the committed PMC passes (profiles/), or None."""
+def load_traffic(name, with_source=False):
+    """HBM bytes per onesweep launch from the committed PMC passes (profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE collected by tools/profile_round.sh, NOT measured in this run), or None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(p) as f:
-            return json.load(f).get(name)
+            d = json.load(f)
+        return (d.get(name), d.get("_source")) if with_source else d.get(name)
     except (OSError, ValueError):
-        return None
+        return (None, None) if with_source else None
 
 
 def main():

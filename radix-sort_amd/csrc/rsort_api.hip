@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "rsort_transfer.hpp"
 #include "rsort_kernels.hpp"
@@ -119,6 +120,7 @@ struct rs_ctx {
   bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
   bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create (and cleared by rs_ctx_set_tile_order)
   bool per_xcd_probe_ok = false;     // what the probe found
+  bool desc_local = false;           // chain-mode descriptors may be published with workgroup-scope stores (chain_probe_kernel in rs_ctx_create)
   int cus = 256;                     // compute units of the device (persistent grids: 2 workgroups each)
   char* static_scratch = nullptr;    // this device's copy of rs_static_scratch (rs_sort_keys_device_noalloc)
   bool static_used = false;          // this context has queued a sort on it (or captured one into a graph that may replay at any time): its error word
@@ -699,6 +701,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       a.chain_cnt_stride = done == 0 ? rsk::kChainHistStride : rsk::kRadix;
       a.chain_tiles = chain_tiles;
       a.chunk_shift = chunk_shift; a.chunk_mul = chunk_mul;
+      a.desc_local = c->desc_local ? 1 : 0;
       if (done + 1 < n_live) {
         a.next_cnt = next_cnt + static_cast<size_t>(done) * rsk::kXcds * rsk::kRadix;
         a.next_shift = begin_bit + live[done + 1] * rsk::kRadixBits;
@@ -983,6 +986,37 @@ int rs_ctx_create(rs_ctx** out, int device) {
       c->per_xcd_probe_ok = ok;
     }
   }
+  // Chain mode publishes its look-back descriptors with workgroup-scope stores and reads them from other workgroups of the
+  // same XCD (rsk::chain_probe_kernel has the reasoning): probed here with the very store / load pair, 128 links per XCD.
+  // Any failure, of a wait or of the probe itself, selects agent-scope stores (correct under the memory model, slower).
+  // RSORT_CHAIN_PROBE=fail forces that (tests, A/B timing).
+  if (c->per_xcd_probe_ok) {
+    const char* env = std::getenv("RSORT_CHAIN_PROBE");
+    constexpr unsigned kLinks = 128;
+    constexpr size_t kBytes = rsk::kXcds * 32 * sizeof(unsigned) + rsk::kXcds * kLinks * sizeof(uint32_t) + sizeof(unsigned);
+    char* d = nullptr;
+    unsigned failures = 1;
+    if (!(env && std::strcmp(env, "fail") == 0) && hipMalloc(reinterpret_cast<void**>(&d), kBytes) == hipSuccess) {
+      if (hipMemsetAsync(d, 0, kBytes, c->stream) == hipSuccess) {
+        auto* tickets = reinterpret_cast<unsigned*>(d);
+        auto* words = reinterpret_cast<uint32_t*>(d + rsk::kXcds * 32 * sizeof(unsigned));
+        auto* fails = reinterpret_cast<unsigned*>(d + kBytes - sizeof(unsigned));
+        hipLaunchKernelGGL(rsk::chain_probe_kernel, dim3(rsk::kXcds * kLinks), dim3(64), 0, c->stream, tickets, words, kLinks, fails);
+        std::vector<uint32_t> h_words(rsk::kXcds * kLinks);
+        if (hipMemcpyAsync(&failures, fails, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(h_words.data(), words, h_words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+          failures = 1;
+        // every link of every chain must have been published (a chain cut short -- an XCD that got fewer workgroups than
+        // links -- proves nothing about the links behind the cut: at least half of each chain is asked for)
+        for (unsigned x = 0; failures == 0 && x < rsk::kXcds; ++x)
+          for (unsigned k = 0; k < kLinks / 2; ++k)
+            if (h_words[x * kLinks + k] != (0x40000000u | k)) { failures = 1; break; }
+      }
+      (void)hipFree(d);
+    }
+    c->desc_local = failures == 0;
+  }
   *out = c;
   return RS_OK;
 }
@@ -1049,6 +1083,7 @@ int rs_debug_set_group_limit(rs_ctx* c, unsigned max_vec) {
   return RS_OK;
 }
 int rs_debug_last_hybrid(const rs_ctx* c) { return c && c->last_hybrid ? 1 : 0; }
+int rs_debug_desc_local(const rs_ctx* c) { return c && c->desc_local ? 1 : 0; }      // what the chain probe of rs_ctx_create found
 
 int rs_ctx_set_tile_order(rs_ctx* c, int per_xcd) {
   if (!c) return RS_ERR_ARG;

@@ -450,6 +450,8 @@ struct SweepArgs {
                                          // pass' output (accumulated here); null in the last pass
   int next_shift, next_bits;             // the next launched pass' digit
   unsigned chunk_shift, chunk_mul;       // chain of output position o = (mul_u24(o >> chunk_shift, chunk_mul)) >> 16
+  int desc_local;                        // descriptors published with workgroup-scope stores (chain_probe_kernel found them visible to the other
+                                         // workgroups of the XCD); 0: agent-scope stores, as the one-chain kernels use
   // Mid-size keys-only sorts (rsort_api.hip): the host queues every kernel of BOTH forms without looking at a count, and
   // each kernel decides for itself, from the top digit's 256 counts, which form is running -- the same answer in all of
   // them.  When every group of equal top digit fits the group kernel's LDS window (rsk::group_sort_mid_kernel), the sort is
@@ -487,6 +489,29 @@ template <bool LOCAL = false, typename D> __device__ __forceinline__ void desc_s
 }
 template <bool C, typename A, typename B> struct Pick { using type = A; };
 template <typename A, typename B> struct Pick<false, A, B> { using type = B; };
+
+// Probe for what chain mode assumes of the memory system: a descriptor published with a WORKGROUP-scope store (desc_store<true>:
+// the line stays in the XCD's L2, no write-through) is seen by an agent-scope load (desc_load) of ANOTHER workgroup on the same
+// XCD.  True on gfx950 (one L2 per XCD, the vector L1 writes through to it), but nothing in the HSA memory model promises it.
+// One-wave workgroups take a ticket from their XCD's counter; ticket k waits for word k - 1 of its XCD's chain (bounded:
+// ~200 us of wall clock) and then publishes word k with exactly the pair the sweep uses.  A chain that does not get
+// through -- any wait that expires -- is counted in failures, and the context then publishes with agent-scope stores.
+__global__ __launch_bounds__(64) void chain_probe_kernel(unsigned* tickets /* [kXcds * 32] */, uint32_t* words /* [kXcds][links] */,
+                                                         unsigned links, unsigned* failures) {
+  if (threadIdx.x != 0) return;
+  const unsigned x = xcc_id();
+  const unsigned k = atomicAdd(&tickets[x * 32], 1u);
+  if (k >= links) return;
+  uint32_t* chain = words + static_cast<size_t>(x) * links;
+  if (k > 0) {
+    const long long t0 = static_cast<long long>(wall_clock64());
+    while (desc_load(&chain[k - 1]) != (0x40000000u | (k - 1))) {
+      __builtin_amdgcn_s_sleep(1);
+      if (static_cast<long long>(wall_clock64()) - t0 > 20000ll) { atomicAdd(failures, 1u); break; }      // 100 MHz ticks
+    }
+  }
+  desc_store<true>(&chain[k], 0x40000000u | k);       // (published even after a failed wait: the workgroups behind must not all time out in turn)
+}
 
 // Bounded wait helper: call once per unsuccessful poll; true = give up (timeout, or another
 // workgroup already reported a fault).  ~2 s of wall clock (s_memrealtime ticks at 100 MHz).
@@ -1019,7 +1044,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     for (int w = 0; w < WAVES; ++w) sum += s.whist[w][tid];
     my_count = sum;
     D word = (static_cast<D>(tile == first_tile ? a.incl_code : kCodeAgg) << Desc<D>::kShift) | static_cast<D>(sum);
-    desc_store<CHAIN>(&desc[tile * kRadix + tid], word);
+    if (CHAIN && a.desc_local) desc_store<true>(&desc[tile * kRadix + tid], word); else desc_store<false>(&desc[tile * kRadix + tid], word);
     unsigned v = sum;
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -1138,7 +1163,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
       if (failed) __hip_atomic_fetch_or(a.error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       D word = (static_cast<D>(a.incl_code) << Desc<D>::kShift) |
                (static_cast<D>(excl + my_count) & Desc<D>::kValueMask);
-      desc_store<CHAIN>(&desc[tile * kRadix + tid], word);
+      if (CHAIN && a.desc_local) desc_store<true>(&desc[tile * kRadix + tid], word); else desc_store<false>(&desc[tile * kRadix + tid], word);
     }
     unsigned long long run_begin = excl;
     if constexpr (CHAIN) run_begin += cs.cbase[tid];

@@ -57,12 +57,16 @@ def test_precheck_paths(engine, oracle):
     assert engine.sort_keys_host(v, 1).tobytes() == np.sort(v).tobytes()
 
 
-@pytest.mark.parametrize("switch", ["RSORT_FORCE_WIDE=1", "RSORT_XCD=0", "RSORT_RANK=ballot"])
+@pytest.mark.parametrize("switch", ["RSORT_FORCE_WIDE=1", "RSORT_XCD=0", "RSORT_RANK=ballot",
+                                    "RSORT_CHAIN_PROBE=fail,RSORT_CHAIN_MIN_TILES=16", "RSORT_CHAIN_MIN_TILES=16"])
 def test_alternate_paths(oracle, switch):
     """Paths the product takes only in special situations, forced at test sizes (a child process each, because the
     switches are read once per process): RSORT_FORCE_WIDE=1 -- 8-byte look-back descriptors and offsets (n > 2^30);
     RSORT_XCD=0 -- one ticket counter instead of one per XCD (what a failed XCC-id probe selects);
-    RSORT_RANK=ballot -- ballot/bitop3 ranking (what a failed LDS lane-order probe selects)."""
+    RSORT_RANK=ballot -- ballot/bitop3 ranking (what a failed LDS lane-order probe selects);
+    RSORT_CHAIN_PROBE=fail -- chain-mode descriptors published with agent-scope stores (what a failed chain probe of
+    rs_ctx_create selects), with chain mode itself forced at test sizes by RSORT_CHAIN_MIN_TILES; the same without the
+    forced failure checks that the probe PASSES on this device (the context then reports workgroup-scope stores)."""
     import os
     import subprocess
     import sys
@@ -74,6 +78,8 @@ import radix_sort_amd as rs
 from radix_sort_amd import shapes
 from cpu_checkers import load_oracle
 orc = load_oracle(); eng = rs.Engine(0); eng.set_precheck(False)
+if "RSORT_CHAIN_MIN_TILES" in os.environ:
+    assert eng.lib.rs_debug_desc_local(eng.h) == (0 if os.environ.get("RSORT_CHAIN_PROBE") == "fail" else 1), "chain probe"
 for name in ("u32", "u64", "f64", "i16"):
     dt, kb, xf = shapes.KEY_TYPES[name]
     for shape in ("randomized", "duplicates", "sorted"):
@@ -87,8 +93,7 @@ assert gk.tobytes() == wk.tobytes() and (gp == wp).all()
 print("WIDE OK")
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    name, value = switch.split("=")
-    env = dict(os.environ, **{name: value})
+    env = dict(os.environ, **dict(kv.split("=") for kv in switch.split(",")))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "WIDE OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
