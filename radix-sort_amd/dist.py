@@ -26,6 +26,12 @@ at the exact quantile: each rank checks its part (all remaining digits constant)
 all-gather compares the values, and the cut takes the bucket's keys in (source rank, position)
 order, so equal keys keep their global input order and the payload variant stays stable.
 
+Overlap (stages > 1, or RSORT_DIST_STAGES=S): every destination's key range is cut into S sub-ranges at top-digit edges
+(each source's keys of one destination and one sub-range are contiguous after the local MSD partition), the exchange
+becomes S smaller all-to-alls posted back to back on the communication stream, and sub-range s is sorted locally
+-- an independent sort: the sub-ranges are disjoint and ordered -- while sub-range s + 1 is still in flight.  The result is
+the concatenation of the sorted sub-ranges.  Keys and payload of a stage travel in one grouped exchange.
+
 `stats` (a dict) makes distributed_sort record per-phase wall times (with a device synchronisation
 at each phase end, so only for diagnosis) and the bytes this rank sent; dist_bench.py runs one such
 sort after the timed ones.
@@ -119,6 +125,54 @@ def exchange_counts(level1_all, level2_all, split16, world, inner_cuts=None):
     return np.diff(below, axis=1)
 
 
+def stage_cuts(level1_all: np.ndarray, split16: np.ndarray, world: int, stages: int) -> np.ndarray:
+    """cuts[r][0..S]: destination r's prefix range [split16[r], split16[r+1]) cut into S sub-ranges, interior cuts on
+    top-digit edges (multiples of 256) nearest to the equal-count points of the destination's keys; non-decreasing, so a
+    destination whose range spans fewer than S top-digit values gets empty sub-ranges."""
+    g1 = level1_all.sum(axis=0).astype(np.int64)
+    cum_edge = np.concatenate(([0], np.cumsum(g1)))                        # keys below top-digit edge e (e = 0..256)
+    cuts = np.zeros((world, stages + 1), dtype=np.int64)
+    for r in range(world):
+        lo, hi = int(split16[r]), int(split16[r + 1])
+        cuts[r, 0], cuts[r, stages] = lo, hi
+        e_lo, e_hi = (lo + 255) >> 8, hi >> 8                              # top-digit edges inside [lo, hi]
+        for s in range(1, stages):
+            if e_lo > e_hi:
+                cuts[r, s] = lo
+                continue
+            below_lo, below_hi = cum_edge[e_lo], cum_edge[e_hi]
+            want = below_lo + (below_hi - below_lo) * s // stages
+            e = int(np.clip(np.searchsorted(cum_edge, want, side="left"), e_lo, e_hi))
+            if e > e_lo and abs(cum_edge[e - 1] - want) <= abs(cum_edge[e] - want):
+                e -= 1
+            cuts[r, s] = min(max(e << 8, lo), hi)
+        cuts[r] = np.maximum.accumulate(cuts[r])
+    return cuts
+
+
+def stage_counts(level1_all, level2_all, split16, cuts, world, inner_cuts=None):
+    """seg[i][r][s] = keys source i sends to destination r in stage s (their sum over s is exchange_counts[i][r]), and
+    off[i][r][s] = where that piece starts in source i's partitioned array."""
+    stages = cuts.shape[1] - 1
+    dest = exchange_counts(level1_all, level2_all, split16, world, inner_cuts)     # [G, G]
+    dest_off = np.concatenate((np.zeros((world, 1), dtype=np.int64), np.cumsum(dest, axis=1)), axis=1)   # [G, G + 1]
+    seg = np.zeros((world, world, stages), dtype=np.int64)
+    off = np.zeros((world, world, stages), dtype=np.int64)
+    for i in range(world):
+        l2 = {b: t[i] for b, t in level2_all.items()}
+        for r in range(world):
+            pts = [int(dest_off[i, r])]
+            for s in range(1, stages):
+                x = int(cuts[r, s])
+                below = count_below(level1_all[i], l2, x) if (x & 255) == 0 or (x >> 8) in l2 else int(dest_off[i, r])
+                pts.append(int(np.clip(below, dest_off[i, r], dest_off[i, r + 1])))
+            pts.append(int(dest_off[i, r + 1]))
+            pts = np.maximum.accumulate(np.array(pts, dtype=np.int64))
+            seg[i, r] = np.diff(pts)
+            off[i, r] = pts[:-1]
+    return seg, off
+
+
 def bucket_counts(level1_all, level2_all, x16):
     """[G] keys with 16-bit prefix x16 on every rank (x16 on a top-digit edge of an unrefined bucket = that whole bucket)."""
     b, s2 = x16 >> 8, x16 & 255
@@ -184,6 +238,42 @@ class Comm:
             self.dist.all_to_all_single(r, sb.cpu(), output_split_sizes=outs, input_split_sizes=ins, group=self.group)
             rb.copy_(r)
         return recv
+
+
+    def exchange_pieces(self, send_lists, recv_lists):
+        """One stage of the staged exchange: for every array (keys, and the payload with them) a list of G send pieces and
+        G receive pieces (views; piece r goes to / comes from rank r).  Returns an object whose wait() makes the pieces
+        usable.  RCCL: all arrays of the stage in flight together on the communication stream, the call does not wait;
+        gloo (CPU tests, one-GPU rehearsal): staged through host memory, done when the call returns."""
+        import torch
+
+        def as_bytes(t):
+            return t if t.dtype in (torch.int8, torch.uint8, torch.int32, torch.int64) else t.view(torch.uint8)
+
+        if self.backend == "nccl":
+            works = [self.dist.all_to_all([as_bytes(t) for t in recv], [as_bytes(t) for t in send], group=self.group, async_op=True)
+                     for send, recv in zip(send_lists, recv_lists)]
+
+            class _Pending:
+                def wait(self_inner):
+                    for w in works:
+                        w.wait()
+            return _Pending()
+        for send, recv in zip(send_lists, recv_lists):
+            sb = torch.cat([as_bytes(t).reshape(-1).cpu() for t in send]) if send else torch.empty(0)
+            ins = [as_bytes(t).numel() for t in send]
+            outs = [as_bytes(t).numel() for t in recv]
+            rb = torch.empty(sum(outs), dtype=sb.dtype)
+            self.dist.all_to_all_single(rb, sb, output_split_sizes=outs, input_split_sizes=ins, group=self.group)
+            at = 0
+            for t, m in zip(recv, outs):
+                as_bytes(t).reshape(-1).copy_(rb[at:at + m])
+                at += m
+
+        class _Done:
+            def wait(self_inner):
+                pass
+        return _Done()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -272,7 +362,15 @@ class HipLocal:
 # ---------------------------------------------------------------------------------------------
 # the distributed sort
 # ---------------------------------------------------------------------------------------------
-def distributed_sort(keys, local, comm: Comm, values=None, stats=None):
+def default_stages() -> int:
+    import os
+    try:
+        return max(1, int(os.environ.get("RSORT_DIST_STAGES", "1")))
+    except ValueError:
+        return 1
+
+
+def distributed_sort(keys, local, comm: Comm, values=None, stats=None, stages=None):
     """keys: this rank's 1-D tensor of raw key bits (int32 / int64 ...).  Returns this rank's slice of
     the globally sorted sequence (a new tensor); `keys` (and `values`) are used as scratch and are clobbered.
 
@@ -284,7 +382,11 @@ def distributed_sort(keys, local, comm: Comm, values=None, stats=None):
     permutation the reference's projected sort applies (radix_sort.hpp:1111-1154).
 
     stats: optional dict; receives {"phase_ms": {...}, "bytes_sent": ..., "keys_received": ...} (adds a device
-    synchronisation at the end of every phase)."""
+    synchronisation at the end of every phase).
+
+    stages: sub-ranges per destination for the pipelined exchange (module docstring); None = RSORT_DIST_STAGES or 1 (one
+    all-to-all, then one local sort -- the unpipelined form)."""
+    stages = default_stages() if stages is None else max(1, int(stages))
     import time
     world = comm.world
     n = keys.numel()
@@ -380,6 +482,10 @@ def distributed_sort(keys, local, comm: Comm, values=None, stats=None):
     counts = exchange_counts(level1_all, level2_all, split16, world, inner_cuts)
     send_counts, recv_counts = counts[comm.rank], counts[:, comm.rank]
 
+    if stages > 1 and two_levels:
+        return _staged_exchange_and_sort(keys, values, scratch, vscratch, local, comm, level1_all, level2_all, split16, inner_cuts,
+                                         stages, stats, phase, phase_ms)
+
     # 5. exchange
     local.synchronize()
     recv = local.empty_like(keys, int(recv_counts.sum()))
@@ -402,4 +508,57 @@ def distributed_sort(keys, local, comm: Comm, values=None, stats=None):
         stats["phase_ms"] = phase_ms
         stats["bytes_sent"] = int((send_counts.sum() - send_counts[comm.rank]) * elem)
         stats["keys_received"] = int(recv_counts.sum())
+    return recv if values is None else (recv, vrecv)
+
+
+def _staged_exchange_and_sort(keys, values, scratch, vscratch, local, comm, level1_all, level2_all, split16, inner_cuts, stages, stats,
+                              phase, phase_ms):
+    """Steps 5 and 6 of distributed_sort in S stages: the exchange of stage s + 1 is in flight while stage s is sorted."""
+    import time
+    world, me = comm.world, comm.rank
+    cuts = stage_cuts(level1_all, split16, world, stages)
+    seg, off = stage_counts(level1_all, level2_all, split16, cuts, world, inner_cuts)
+    recv_sizes = seg[:, me, :]                                             # [source, stage]
+    stage_total = recv_sizes.sum(axis=0)                                   # keys this rank receives per stage
+    stage_start = np.concatenate(([0], np.cumsum(stage_total)))
+    total_recv = int(stage_total.sum())
+    recv = local.empty_like(keys, total_recv)
+    vrecv = local.empty_like(values, total_recv) if values is not None else None
+
+    def pieces(s):
+        send_k = [keys.narrow(0, int(off[me, r, s]), int(seg[me, r, s])) for r in range(world)]
+        at = int(stage_start[s]) + np.concatenate(([0], np.cumsum(recv_sizes[:, s])))
+        recv_k = [recv.narrow(0, int(at[i]), int(recv_sizes[i, s])) for i in range(world)]
+        if values is None:
+            return [send_k], [recv_k]
+        send_v = [values.narrow(0, int(off[me, r, s]), int(seg[me, r, s])) for r in range(world)]
+        recv_v = [vrecv.narrow(0, int(at[i]), int(recv_sizes[i, s])) for i in range(world)]
+        return [send_k, send_v], [recv_k, recv_v]
+
+    local.synchronize()                                                    # the partition passes that wrote `keys` are done
+    t_begin = time.perf_counter()
+    stage_ms = []
+    pending = comm.exchange_pieces(*pieces(0))
+    for s in range(stages):
+        nxt = comm.exchange_pieces(*pieces(s + 1)) if s + 1 < stages else None     # in flight while stage s is sorted
+        pending.wait()
+        local.wait_for_producers(recv)
+        lo, m = int(stage_start[s]), int(stage_total[s])
+        if m > 1:
+            local.sort(recv.narrow(0, lo, m), scratch if scratch.numel() >= m else None,
+                       vrecv.narrow(0, lo, m) if vrecv is not None else None,
+                       vscratch if vscratch is not None and vscratch.numel() >= m else None)
+        if stats is not None:
+            local.synchronize()
+            stage_ms.append(round((time.perf_counter() - t_begin) * 1e3, 3))      # when stage s was exchanged AND sorted
+        pending = nxt
+    local.synchronize()
+    phase("exchange_and_local_sort_pipelined")
+    if stats is not None:
+        elem = keys.element_size() + (values.element_size() if values is not None else 0)
+        stats["phase_ms"] = phase_ms
+        stats["stage_done_ms"] = stage_ms
+        stats["stages"] = stages
+        stats["bytes_sent"] = int((seg[me].sum() - seg[me, me].sum()) * elem)
+        stats["keys_received"] = total_recv
     return recv if values is None else (recv, vrecv)

@@ -76,6 +76,8 @@ def _run_type(args, name, rank, world, dev):
     src = shapes.generate_device(name, n, shape, dev, seed=shapes.SEED + rank)
     work = torch.empty_like(src)
 
+    stages = rsd.default_stages()                  # RSORT_DIST_STAGES: 1 = one all-to-all then one local sort; S > 1 = pipelined (dist.py)
+    torch.cuda.reset_peak_memory_stats(dev)
     times, pass_ms = [], []
     out = None
     for it in range(args.warmup + args.steps):
@@ -84,7 +86,7 @@ def _run_type(args, name, rank, world, dev):
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        out = rsd.distributed_sort(work, local, comm)
+        out = rsd.distributed_sort(work, local, comm, stages=stages)
         torch.cuda.synchronize()
         dist.barrier()
         t1 = time.perf_counter()
@@ -97,9 +99,13 @@ def _run_type(args, name, rank, world, dev):
     torch.cuda.synchronize()
     dist.barrier()
     st = {}
-    out = rsd.distributed_sort(work, local, comm, stats=st)
+    out = rsd.distributed_sort(work, local, comm, stats=st, stages=stages)
     torch.cuda.synchronize()
-    names = ["partition_top_digit", "gather_tables", "refine_second_digit", "equal_key_buckets", "exchange", "local_sort"]
+    free_b, total_b = torch.cuda.mem_get_info(dev)                          # device-wide: torch's tensors AND the library's own workspace
+    mem = torch.tensor([float(torch.cuda.max_memory_allocated(dev)), float(total_b - free_b)], dtype=torch.float64, device=cdev)
+    dist.all_reduce(mem, op=dist.ReduceOp.MAX)
+    names = ["partition_top_digit", "gather_tables", "refine_second_digit", "equal_key_buckets", "exchange", "local_sort",
+             "exchange_and_local_sort_pipelined"]
     ph = torch.tensor([st["phase_ms"].get(k, 0.0) for k in names] + [float(st["bytes_sent"])], dtype=torch.float64, device=cdev)
     ph_max = ph.clone()
     dist.all_reduce(ph_max, op=dist.ReduceOp.MAX)
@@ -134,8 +140,11 @@ def _run_type(args, name, rank, world, dev):
                       "count_kept": s[0] == s[2], "checksum_kept": s[1] == s[3]},
            "keys_per_rank_after_exchange": sizes.cpu().tolist(),
            "phase_ms_max_over_ranks": phase_ms,          # from the extra, synchronised sort: where a step's time goes
+           "stages": stages,                              # RSORT_DIST_STAGES (1 = unpipelined)
+           "stage_done_ms_rank0": st.get("stage_done_ms"),   # pipelined form: when each stage was exchanged and sorted, from the first post
+           "peak_device_bytes_max_over_ranks": {"torch_tensors": int(mem[0].item()), "device_in_use_after_sort": int(mem[1].item())},
            "bytes_sent_all_ranks": bytes_sent_total,
-           "exchange_gbs_per_rank": (bytes_sent_total / world / (phase_ms["exchange"] * 1e-3) / 1e9) if phase_ms["exchange"] > 0 else None,
+           "exchange_gbs_per_rank": (bytes_sent_total / world / (phase_ms["exchange"] * 1e-3) / 1e9) if phase_ms["exchange"] > 0 else None,   # (unpipelined form only)
            "roofline": {"bound": "hbm", "kernel": f"onesweep_kernel<{name}> (local sort, rank 0)", "achieved": achieved,
                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0 if achieved else None, "traffic": None}}
     del out, work, src

@@ -52,7 +52,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, name, shape, n_per_rank, outdir):
+def _worker(rank, world, port, name, shape, n_per_rank, outdir, stages=1):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import radix_sort_amd  # noqa: F401
     from dist_cpu_backend import NumpyLocal
@@ -65,7 +65,7 @@ def _worker(rank, world, port, name, shape, n_per_rank, outdir):
         bounds[1] += 5 if world > 1 else 0               # ragged shards
         mine = full[bounds[rank]:bounds[rank + 1]].copy()
         t = torch.from_numpy(mine.view({1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[kb]))
-        out = rsd.distributed_sort(t, NumpyLocal(kb, xf), rsd.Comm())
+        out = rsd.distributed_sort(t, NumpyLocal(kb, xf), rsd.Comm(), stages=stages)
         np.save(os.path.join(outdir, f"out{rank}.npy"), out.numpy())
     finally:
         dist.destroy_process_group()
@@ -75,9 +75,12 @@ def _worker(rank, world, port, name, shape, n_per_rank, outdir):
 @pytest.mark.parametrize("name,shape", [("u64", "randomized"), ("u64", "duplicates"), ("u32", "sorted"),
                                         ("i64", "nearly_sorted"), ("f64", "randomized"), ("u8", "randomized"),
                                         ("u32", "reverse_sorted")])
-def test_distributed_sort_gloo(tmp_path, oracle, world, name, shape):
+@pytest.mark.parametrize("stages", [1, 4])
+def test_distributed_sort_gloo(tmp_path, oracle, world, name, shape, stages):
+    """stages = 4: the pipelined exchange -- every destination's range in four sub-ranges, each exchanged and sorted on
+    its own (RSORT_DIST_STAGES)."""
     n_per_rank = 20_000
-    mp.spawn(_worker, args=(world, _free_port(), name, shape, n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), name, shape, n_per_rank, str(tmp_path), stages), nprocs=world, join=True)
     dt, kb, xf = shapes.KEY_TYPES[name]
     full = shapes.generate(name, n_per_rank * world + 17, shape)
     got = np.concatenate([np.load(tmp_path / f"out{r}.npy") for r in range(world)])
@@ -88,7 +91,7 @@ def test_distributed_sort_gloo(tmp_path, oracle, world, name, shape):
         assert max(sizes) - min(sizes) <= full.size // 100 + 64
 
 
-def _pair_worker(rank, world, port, name, shape, n_per_rank, outdir):
+def _pair_worker(rank, world, port, name, shape, n_per_rank, outdir, stages=1):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import radix_sort_amd  # noqa: F401
     from dist_cpu_backend import NumpyLocal
@@ -102,7 +105,7 @@ def _pair_worker(rank, world, port, name, shape, n_per_rank, outdir):
         mine = full[bounds[rank]:bounds[rank + 1]].copy()
         t = torch.from_numpy(mine.view({1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[kb]))
         idx = torch.arange(bounds[rank], bounds[rank + 1], dtype=torch.int64)       # global positions as payload
-        k, v = rsd.distributed_sort(t, NumpyLocal(kb, xf), rsd.Comm(), values=idx)
+        k, v = rsd.distributed_sort(t, NumpyLocal(kb, xf), rsd.Comm(), values=idx, stages=stages)
         np.save(os.path.join(outdir, f"k{rank}.npy"), k.numpy())
         np.save(os.path.join(outdir, f"v{rank}.npy"), v.numpy())
     finally:
@@ -111,11 +114,12 @@ def _pair_worker(rank, world, port, name, shape, n_per_rank, outdir):
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("name,shape", [("u64", "duplicates"), ("i32", "duplicates"), ("f64", "randomized"), ("u16", "randomized")])
-def test_distributed_pairs_are_stable_gloo(tmp_path, oracle, world, name, shape):
+@pytest.mark.parametrize("stages", [1, 4])
+def test_distributed_pairs_are_stable_gloo(tmp_path, oracle, world, name, shape, stages):
     """Keys + payload across ranks: the payload (global input positions) must come back as the reference's stable
     permutation (key path, radix_sort.hpp:1160-1206 / sortByIndices :1111-1154)."""
     n_per_rank = 15_000
-    mp.spawn(_pair_worker, args=(world, _free_port(), name, shape, n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_pair_worker, args=(world, _free_port(), name, shape, n_per_rank, str(tmp_path), stages), nprocs=world, join=True)
     dt, kb, xf = shapes.KEY_TYPES[name]
     full = shapes.generate(name, n_per_rank * world + 17, shape)
     gk = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
@@ -125,13 +129,14 @@ def test_distributed_pairs_are_stable_gloo(tmp_path, oracle, world, name, shape)
     assert np.array_equal(gv.astype(np.uint64), wp.astype(np.uint64))
 
 
+@pytest.mark.parametrize("stages", [1, 4])
 @pytest.mark.parametrize("shape", ["randomized", "sorted", "reverse_sorted", "nearly_sorted", "duplicates"])
-def test_world8_all_shapes_sorted_and_balanced(tmp_path, oracle, shape):
+def test_world8_all_shapes_sorted_and_balanced(tmp_path, oracle, shape, stages):
     """BASELINE configs[4] rehearsed on CPU: 8 ranks, uint64 keys, every generator shape -- the exact global order, and
     after the exchange no rank holds much more than its share (the 256-value duplicates shape included: buckets of equal
     keys are cut by count)."""
     world, n_per_rank = 8, 12_000
-    mp.spawn(_worker, args=(world, _free_port(), "u64", shape, n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), "u64", shape, n_per_rank, str(tmp_path), stages), nprocs=world, join=True)
     full = shapes.generate("u64", n_per_rank * world + 17, shape)
     outs = [np.load(tmp_path / f"out{r}.npy") for r in range(world)]
     assert np.concatenate(outs).tobytes() == oracle.sort_keys(full, 0, mt=True).tobytes()
@@ -139,10 +144,11 @@ def test_world8_all_shapes_sorted_and_balanced(tmp_path, oracle, shape):
     assert sizes.max() / sizes.mean() <= (1.3 if shape == "duplicates" else 1.05), sizes
 
 
-def test_world8_stable_pairs_on_duplicates(tmp_path, oracle):
+@pytest.mark.parametrize("stages", [1, 4])
+def test_world8_stable_pairs_on_duplicates(tmp_path, oracle, stages):
     """Equal-key buckets cut by count must keep the global input order of the equal keys (payload = global position)."""
     world, n_per_rank = 8, 6_000
-    mp.spawn(_pair_worker, args=(world, _free_port(), "u32", "duplicates", n_per_rank, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_pair_worker, args=(world, _free_port(), "u32", "duplicates", n_per_rank, str(tmp_path), stages), nprocs=world, join=True)
     full = shapes.generate("u32", n_per_rank * world + 17, "duplicates")
     gk = np.concatenate([np.load(tmp_path / f"k{r}.npy") for r in range(world)])
     gv = np.concatenate([np.load(tmp_path / f"v{r}.npy") for r in range(world)])
@@ -151,6 +157,31 @@ def test_world8_stable_pairs_on_duplicates(tmp_path, oracle):
     assert np.array_equal(gv.astype(np.uint64), wp.astype(np.uint64))
     sizes = np.array([np.load(tmp_path / f"k{r}.npy").size for r in range(world)], dtype=np.float64)
     assert sizes.max() / sizes.mean() <= 1.3, sizes
+
+
+def test_stage_pieces_tile_every_destination():
+    """Planning only: the staged exchange's pieces are, for every source and destination, a partition of exactly the keys
+    the unstaged exchange sends, in order; a destination spanning fewer top-digit values than stages gets empty pieces."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    for world, stages in ((2, 4), (3, 4), (8, 4), (8, 64)):
+        keys = [rng.integers(0, 1 << 32, 30_000, dtype=np.uint64).astype(np.uint32) for _ in range(world)]
+        l1 = np.stack([np.bincount((k >> 24).astype(np.int64), minlength=256) for k in keys])
+        refine = rsd.boundary_buckets(l1, world)
+        l2 = {b: np.stack([np.bincount(((k[(k >> 24) == b] >> 16) & 255).astype(np.int64), minlength=256) for k in keys]) for b in refine}
+        split = rsd.plan_splits(l1, l2, world)
+        cuts = rsd.stage_cuts(l1, split, world, stages)
+        assert (np.diff(cuts, axis=1) >= 0).all() and (cuts[:, 0] == split[:-1]).all() and (cuts[:, -1] == split[1:]).all()
+        seg, off = rsd.stage_counts(l1, l2, split, cuts, world)
+        dest = rsd.exchange_counts(l1, l2, split, world)
+        assert (seg.sum(axis=2) == dest).all() and (seg >= 0).all()
+        for i in range(world):
+            assert (np.diff(off[i].reshape(-1)) == seg[i].reshape(-1)[:-1]).all() and off[i, 0, 0] == 0
+            order = np.sort(keys[i] >> 16)                     # the source's keys by 16-bit prefix, as its partition passes leave them
+            for r in range(world):
+                for s in range(stages):
+                    piece = order[off[i, r, s]: off[i, r, s] + seg[i, r, s]]
+                    assert ((piece >= cuts[r, s]) & (piece < max(cuts[r, s + 1], cuts[r, s] + (piece.size > 0)))).all() or \
+                           ((piece >= cuts[r, s]) & (piece <= cuts[r, s + 1])).all()
 
 
 def test_equal_key_bucket_is_cut_by_count():
