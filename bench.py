@@ -178,6 +178,7 @@ def bench_single(args):
     pair_rows = [bench_pairs(eng, torch, dev, spec, args) for spec in args.pairs]
     eng.set_profiling(False)
     string_rows = [bench_strings(eng, m) for m in args.strings]
+    string_rows += [bench_strings(eng, args.strings[0], shape) for shape in args.string_shapes if args.strings]
     eng.close()
     return headline, rows, dominant, pair_rows, string_rows
 
@@ -228,16 +229,63 @@ def bench_pairs(eng, torch, dev, spec, args):
             "sorted": ok_sorted, "stable": ok_stable, "checksum": ok_perm}
 
 
-def bench_strings(eng, m):
-    """rs_sort_strings through the C-ABI: m strings of 0..20 uniform bytes (generators.hpp:264-291) in host memory, the
-    permutation back in host memory (upload and download included: the entry point takes host buffers).  Checked:
-    the result is a permutation and 200,000 sampled neighbour pairs are in std::string order, ties by index."""
+def string_workload(m, shape, rng):
+    """(blob, offsets) of m strings, vectorised (the generators of radix-sort_amd/shapes.py loop in Python):
+    randomized  0..20 uniform bytes (generators.hpp:264-291);
+    prefix24    the same behind a 24-byte prefix every string shares (several MSD levels see one chunk value);
+    shortlex    the reference's "sorted" string shape (generators.hpp:319-347): "", the 256 one-byte strings, the 65536
+                two-byte strings, ... in counting order -- NOT std::string order, so it is really sorted;
+    dup256      256 distinct strings of 0..20 bytes drawn uniformly (the "duplicates" shape: large segments at every level)."""
     import numpy as np
-    rng = np.random.default_rng(69)
-    lens = rng.integers(0, 21, size=m, dtype=np.int64)
+    if shape == "shortlex":
+        idx = np.arange(m, dtype=np.int64)
+        lens = np.where(idx < 1, 0, np.where(idx < 257, 1, np.where(idx < 65793, 2, 3)))
+        offsets = np.zeros(m + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:].view(np.int64))
+        blob = np.empty(int(offsets[-1]), dtype=np.uint8)
+        start = offsets[:-1].astype(np.int64)
+        for length, first in ((1, 1), (2, 257), (3, 65793)):
+            sel = np.flatnonzero(lens == length)
+            v = idx[sel] - first
+            for b in range(length):
+                blob[start[sel] + b] = (v >> (8 * (length - 1 - b))) & 255
+        return blob, offsets
+    if shape == "dup256":
+        ulen = rng.integers(0, 21, size=256)
+        tab = rng.integers(0, 256, size=(256, 20), dtype=np.uint8)
+        pick = rng.integers(0, 256, size=m)
+        lens = ulen[pick]
+        offsets = np.zeros(m + 1, dtype=np.uint64)
+        np.cumsum(lens, out=offsets[1:].view(np.int64))
+        blob = np.empty(int(offsets[-1]), dtype=np.uint8)
+        step = 1_000_000
+        for lo in range(0, m, step):                        # (in slices: the mask of a slice is 20 MB, not 200)
+            hi = min(lo + step, m)
+            rows = tab[pick[lo:hi]]
+            mask = np.arange(20)[None, :] < lens[lo:hi, None]
+            blob[int(offsets[lo]):int(offsets[hi])] = rows[mask]
+        return blob, offsets
+    pre = 24 if shape == "prefix24" else 0
+    lens = rng.integers(0, 21, size=m, dtype=np.int64) + pre
     offsets = np.zeros(m + 1, dtype=np.uint64)
     np.cumsum(lens, out=offsets[1:].view(np.int64))
     blob = rng.integers(0, 256, size=int(offsets[-1]), dtype=np.uint8)
+    if pre:
+        start = offsets[:-1].astype(np.int64)
+        for b in range(pre):
+            blob[start + b] = 65 + b
+    return blob, offsets
+
+
+def bench_strings(eng, m, shape="randomized"):
+    """rs_sort_strings32 through the C-ABI: m strings (string_workload) in host memory, the permutation back in host
+    memory (upload and download included: the entry point takes host buffers; 4-byte offsets and permutation, as the
+    front-end passes them for blobs below 4 GiB).  Checked: the result is a permutation and 200,000 sampled neighbour
+    pairs are in std::string order, ties by index."""
+    import numpy as np
+    rng = np.random.default_rng(69)
+    blob, offsets = string_workload(m, shape, rng)
+    off32 = offsets.astype(np.uint32)                                       # what the front-end packs for blobs below 4 GiB
     eng.sort_strings_host(blob[: 1 << 16], offsets[:1001].copy())          # warm-up (context, kernels)
     times, dev_ms = [], []
     eng.set_profiling(True)
@@ -245,7 +293,7 @@ def bench_strings(eng, m):
     eng.set_host_threads(host_threads)
     for _ in range(3):
         t0 = time.perf_counter()
-        perm = eng.sort_strings_host(blob, offsets, stable=True)
+        perm = eng.sort_strings_host(blob, off32, stable=True, narrow=True, widen=False)
         times.append(time.perf_counter() - t0)
         dev_ms.append(sum(eng.profile()))       # HIP events around the device part (between upload and download)
     eng.set_profiling(False)
@@ -262,14 +310,14 @@ def bench_strings(eng, m):
             ok_order = False
             break
     sec = min(times)
-    moved = int(offsets[-1]) + 8 * (m + 1) + 8 * m
+    moved = int(offsets[-1]) + 4 * (m + 1) + 4 * m       # blob + 4-byte offsets up, 4-byte permutation down
     # Algorithmic HBM bytes of the first MSD level per string (every string takes part in it; later levels only the
     # unresolved ones): the chunk kernel reads the offsets (16) and <= 7 string bytes and writes an 8-byte key and a 4-byte
     # id (35); the stable pair sort of (8-byte chunk key, 4-byte id) is canonical K + 2*8*(K+V) = 200; heads, open flags,
     # two scans, the gathers and the write-back of the permutation are about 17 four-byte accesses (68): 303 bytes.
     level0_bytes = 303
     dev = min(dev_ms) if dev_ms and min(dev_ms) > 0 else None
-    return {"strings": m, "ms": sec * 1e3, "mstrings_s": m / sec / 1e6, "host_bytes_per_string": moved / m,
+    return {"strings": m, "shape": shape, "levels": eng.last_string_levels(), "ms": sec * 1e3, "mstrings_s": m / sec / 1e6, "host_bytes_per_string": moved / m,
             "includes": "H2D of blob+offsets, MSD sort, D2H of the permutation", "host_threads": host_threads,
             "device_ms": dev, "device_mstrings_s": m / dev / 1e3 if dev else None,
             "device_bytes_per_string_level0": level0_bytes,
@@ -328,6 +376,7 @@ def main():
     ap.add_argument("--pairs", default="u32+4,u64+4", help="key type + payload bytes")
     ap.add_argument("--pairs-n", type=int, default=1 << 29)
     ap.add_argument("--strings", default="10000000,50000000", help="string counts for the rs_sort_strings rows")
+    ap.add_argument("--string-shapes", default="prefix24,shortlex,dup256", help="harder string inputs, at the first --strings count")
     ap.add_argument("--composite-n", type=int, default=10_000_000, help="0 = skip the configs[3] row")
     ap.add_argument("--cpu-n", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -338,6 +387,7 @@ def main():
     args.extra_shapes = [s for s in args.extra_shapes.split(",") if s]
     args.pairs = [p for p in args.pairs.split(",") if p]
     args.strings = [int(x) for x in args.strings.split(",") if x]
+    args.string_shapes = [x for x in args.string_shapes.split(",") if x]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 or args.gpus > 1 or os.environ.get("RS_BENCH_FORCE_DIST"):

@@ -254,19 +254,21 @@ namespace radix_sort
 				std::swap(tmp, v);
 			}
 
+			// OFF = std::uint32_t when the bytes of all strings stay below 4 GiB (rs_sort_strings32: 18 instead of 26 bytes per
+			// string cross PCIe), std::uint64_t otherwise
+			template <typename OFF>
 			struct PackedStrings
 			{
 				Uninitialized<std::uint8_t> blob;
-				Uninitialized<std::uint64_t> offsets;
+				Uninitialized<OFF> offsets;
 			};
 
+			// bytes of the strings of each of `threads` ranges of v, as running totals: [0] = 0, [threads] = all of them
 			template <typename T, typename Proj>
-			inline PackedStrings packStrings(const std::vector<T>& v, Proj& proj, std::size_t threads)
+			inline std::vector<std::uint64_t> stringRangeBytes(const std::vector<T>& v, Proj& proj, std::size_t threads)
 			{
-				const std::size_t n = v.size();
-				// lengths per range, then the ranges' starting offsets, then offsets and bytes
 				std::vector<std::uint64_t> rangeBytes(std::max<std::size_t>(threads, 1) + 1, 0);
-				forRanges(n, threads, [&](std::size_t lo, std::size_t hi, std::size_t t) {
+				forRanges(v.size(), threads, [&](std::size_t lo, std::size_t hi, std::size_t t) {
 					std::uint64_t total = 0;
 					for (std::size_t i = lo; i < hi; i++)
 						total += std::invoke(proj, v[i]).size();
@@ -274,8 +276,15 @@ namespace radix_sort
 				});
 				for (std::size_t t = 1; t < rangeBytes.size(); t++)
 					rangeBytes[t] += rangeBytes[t - 1];
-				PackedStrings p{Uninitialized<std::uint8_t>(rangeBytes.back()), Uninitialized<std::uint64_t>(n + 1)};
-				p.offsets[n] = rangeBytes.back();
+				return rangeBytes;
+			}
+
+			template <typename OFF, typename T, typename Proj>
+			inline PackedStrings<OFF> packStrings(const std::vector<T>& v, Proj& proj, std::size_t threads, const std::vector<std::uint64_t>& rangeBytes)
+			{
+				const std::size_t n = v.size();
+				PackedStrings<OFF> p{Uninitialized<std::uint8_t>(rangeBytes.back()), Uninitialized<OFF>(n + 1)};
+				p.offsets[n] = static_cast<OFF>(rangeBytes.back());
 				forRanges(n, threads, [&](std::size_t lo, std::size_t hi, std::size_t t) {
 					std::uint64_t at = rangeBytes[t];
 					constexpr std::size_t kAhead = 16;     // the bytes of a string past the small-string size live somewhere on the heap
@@ -287,7 +296,7 @@ namespace radix_sort
 							if (i + kAhead < hi)
 								__builtin_prefetch(std::invoke(proj, v[i + kAhead]).data(), 0, 0);
 						const std::string& s = std::invoke(proj, v[i]);
-						p.offsets[i] = at;
+						p.offsets[i] = static_cast<OFF>(at);
 						std::copy(s.begin(), s.end(), p.blob.data() + at);
 						at += s.size();
 					}
@@ -299,12 +308,23 @@ namespace radix_sort
 			inline void sortByStringKey(std::vector<T>& v, Proj& proj, bool stable, bool enableMultiThreading)
 			{
 				const std::size_t threads = helperThreads(v.size(), enableMultiThreading);
-				PackedStrings p = packStrings(v, proj, threads);
-				Uninitialized<std::uint64_t> perm(v.size());
+				const std::vector<std::uint64_t> rangeBytes = stringRangeBytes(v, proj, threads);
 				rs_ctx* ctx = context();
 				check(ctx, rs_ctx_set_host_threads(ctx, static_cast<int>(hostThreads(v.size(), enableMultiThreading))));
-				check(ctx, rs_sort_strings(ctx, p.blob.data(), p.offsets.data(), v.size(), perm.data(), stable ? 1 : 0));
-				applyPermutation(v, perm.data(), threads);
+				if (rangeBytes.back() < (std::uint64_t(1) << 32) && v.size() < 0xFFFFFFFFull)
+				{
+					PackedStrings<std::uint32_t> p = packStrings<std::uint32_t>(v, proj, threads, rangeBytes);
+					Uninitialized<std::uint32_t> perm(v.size());
+					check(ctx, rs_sort_strings32(ctx, p.blob.data(), p.offsets.data(), v.size(), perm.data(), stable ? 1 : 0));
+					applyPermutation(v, perm.data(), threads);
+				}
+				else
+				{
+					PackedStrings<std::uint64_t> p = packStrings<std::uint64_t>(v, proj, threads, rangeBytes);
+					Uninitialized<std::uint64_t> perm(v.size());
+					check(ctx, rs_sort_strings(ctx, p.blob.data(), p.offsets.data(), v.size(), perm.data(), stable ? 1 : 0));
+					applyPermutation(v, perm.data(), threads);
+				}
 			}
 		}
 

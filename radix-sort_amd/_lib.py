@@ -33,6 +33,7 @@ SYMBOLS = [
     ("rs_sort_pairs", _i, [_vp, _vp, _vp, _sz, _i, _i, _i, _i, _i]),
     ("rs_sort_rows", _i, [_vp, _vp, _sz, _i, _vp, _i, _i]),
     ("rs_sort_strings", _i, [_vp, _vp, _vp, _sz, _vp, _i]),
+    ("rs_sort_strings32", _i, [_vp, _vp, _vp, _sz, _vp, _i]),
 ]
 
 _lib = None

@@ -134,6 +134,8 @@ struct rs_ctx {
   int hybrid_mode = -1;          // hybrid form of 4-byte key sorts: -1 chosen per sort, 0 never, 1 whenever the shape allows (rs_ctx_set_hybrid; RSORT_HYBRID at creation)
   unsigned group_max_vec = 0;    // test hook: groups of more vectors than this go to the big-group kernel (0 = what the LDS window holds)
   bool last_hybrid = false;      // the last sort_device took the hybrid form
+  int last_string_levels = 0;    // MSD levels the last string sort took
+  bool last_all_equal = false;   // the last sort_device read its digit counts and found every key equal on the sorted bits (nothing launched)
   hipEvent_t ev[kMaxPasses + 4] = {};
   hipEvent_t small_up = nullptr;     // after the last small host-to-device copy through lane 0's bounce buffer (to_device)
   bool small_up_pending = false;
@@ -387,6 +389,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
                 int value_bytes, int transform, int begin_bit, int end_bit, const Workspace* ws = nullptr) {
   c->last_unchanged = false;
   c->last_hybrid = false;
+  c->last_all_equal = false;
   if (n < 2) { c->ev_count = 0; return RS_OK; }
   hipStream_t s = c->stream;
   const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
@@ -614,6 +617,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       }
     }
   }
+  c->last_all_equal = !(ws || mid) && n_live == 0;
   // Few-valued 4-byte keys (the 256-value "duplicates" shape: about 160 of 256 bins in use per pass) go down the
   // one-chain kernels: staged in digit order, their equal keys sit next to each other, and the chain kernels' counting adds
   // then cost more than the chained look-back saves (N = 2^30: 11.1 ms against 9.7 ms; 8-byte keys gain either way).
@@ -883,6 +887,127 @@ int finish_host_call(rs_ctx* c) {
   if (rc == RS_OK) hand_over(c);
   c->fetched[0] = c->fetched[1] = {nullptr, 0};
   return rc;
+}
+
+
+// rs_sort_strings / rs_sort_strings32: OFF = type of the offsets AND of the permutation (8 bytes: any blob; 4 bytes: blobs and
+// string counts below 2^32, a third less to move over PCIe, which is 9/10 of the call).
+template <typename OFF>
+int sort_strings_impl(rs_ctx* c, const uint8_t* h_blob, const OFF* h_offsets, size_t n, OFF* h_perm, int stable) {
+  (void)stable;   // every pass is stable and level 0 starts from the identity: one code path serves both
+  if (!c) return RS_ERR_ARG;
+  if (n > 0 && (!h_offsets || !h_perm)) return fail(c, RS_ERR_ARG, "null offsets/perm pointer");
+  if (n >= 0xFFFFFFFFull) return fail(c, RS_ERR_ARG, "string sort takes fewer than 2^32 - 1 strings");
+  if (n == 0) return RS_OK;
+  if (n == 1) { h_perm[0] = 0; return RS_OK; }
+  const uint64_t total = h_offsets[n];
+  if (total > 0 && !h_blob) return fail(c, RS_ERR_ARG, "null blob pointer");
+  HostCall host_call(c);
+  c->fetched[0] = c->fetched[1] = {nullptr, 0};   // nothing left over from a call that failed half-way
+  RS_HIP(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+
+  // carve one device allocation
+  auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+  const size_t m0 = n;
+  const size_t blocks0 = (m0 + rss::kScanTile - 1) / rss::kScanTile;
+  size_t need = up(total + 16) + up((n + 1) * sizeof(OFF)) + 2 * up(m0 * 8) /*keys, keys_alt (also the widened perm)*/ +
+                11 * up(m0 * 4) + up((blocks0 + 2) * 4);
+  int rc;
+  if ((rc = ensure(c, c->strbuf, need)) != RS_OK) return rc;
+  char* p = static_cast<char*>(c->strbuf.p);
+  auto take = [&](size_t b) { char* q = p; p += up(b); return q; };
+  auto* d_blob = reinterpret_cast<uint8_t*>(take(total + 16));
+  auto* d_off = reinterpret_cast<OFF*>(take((n + 1) * sizeof(OFF)));
+  auto* keys = reinterpret_cast<uint64_t*>(take(m0 * 8));
+  auto* keys_alt = reinterpret_cast<uint64_t*>(take(m0 * 8));
+  uint32_t* u[11];
+  for (auto& q : u) q = reinterpret_cast<uint32_t*>(take(m0 * 4));
+  uint32_t *perm = u[0], *val = u[1], *val_alt = u[2], *seg = u[3], *ids = u[4], *ids_sorted_buf = u[5], *pos = u[6], *pos2 = u[7],
+           *head = u[8], *scan_a = u[9], *scan_b = u[10];
+  auto* block_sums = reinterpret_cast<uint32_t*>(take((blocks0 + 2) * 4));
+
+  if (total && (rc = to_device(c, d_blob, h_blob, total, 0)) != RS_OK) return rc;
+  if ((rc = to_device(c, d_off, h_offsets, (n + 1) * sizeof(OFF), 1)) != RS_OK) return rc;
+
+  auto grid = [](size_t m) { return dim3(static_cast<unsigned>((m + rss::kBlock - 1) / rss::kBlock)); };
+  auto scan = [&](const uint32_t* in, size_t m, uint32_t* out, bool inclusive) {
+    unsigned blocks = static_cast<unsigned>((m + rss::kScanTile - 1) / rss::kScanTile);
+    hipLaunchKernelGGL(rss::scan_block_sums_kernel, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums);
+    hipLaunchKernelGGL(rss::scan_spine_kernel, dim3(1), dim3(rss::kBlock), 0, s, block_sums, blocks);
+    if (inclusive) hipLaunchKernelGGL(rss::scan_apply_kernel<true>, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums, out);
+    else hipLaunchKernelGGL(rss::scan_apply_kernel<false>, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums, out);
+    return blocks;
+  };
+
+  const bool prof_strings = c->profiling;
+  if (prof_strings) RS_HIP(c, hipEventRecord(c->ev[0], s));     // the device part: everything between the upload and the download
+  size_t m = n;
+  uint32_t* cur_pos = nullptr;      // level 0: position j is slot j
+  uint32_t* cur_ids = nullptr;      // level 0: slot j is string j; later: `ids`, the compacted ids of the level's slots
+  uint32_t* cur_seg = nullptr;      // level 0: one segment
+  size_t max_seg = 0;               // segment numbers of the level are < max_seg
+  uint64_t depth = 0;               // bytes of every unresolved string already compared
+  const bool prof = c->profiling;
+  const bool precheck = c->precheck;
+  c->profiling = false;             // the per-kernel event slots belong to single sorts
+  c->precheck = false;              // (chunk keys of unordered strings: the order pre-check of each level's sort would only cost its launches)
+  auto restore = [&] { c->profiling = prof; c->precheck = precheck; };
+  uint32_t level = 0;
+  for (;; ++level) {
+    const uint32_t mm = static_cast<uint32_t>(m);
+    unsigned sbits = 0;
+    if (cur_seg)
+      while (sbits < 32 && (size_t(1) << sbits) < max_seg) ++sbits;        // bits that hold every segment number of this level
+    const unsigned cbytes = std::min<unsigned>(rss::kChunkBytes, (56u - sbits) / 8u);
+    hipLaunchKernelGGL(rss::iota_kernel, grid(m), dim3(rss::kBlock), 0, s, val, static_cast<uint32_t*>(nullptr), mm);
+    hipLaunchKernelGGL(rss::chunk_keys_kernel<OFF>, grid(m), dim3(rss::kBlock), 0, s, d_blob, d_off, cur_ids, cur_seg, mm, depth, cbytes, sbits, keys);
+    if ((rc = sort_device(c, keys, val, keys_alt, val_alt, m, 8, 4, RS_XF_NONE, 0, 64)) != RS_OK) { restore(); return rc; }
+    if (c->last_all_equal) {
+      // Every unresolved string has the same chunk key (a prefix all of them share): if the chunk is full, nothing about
+      // them changes at this level -- same set, same order, same segments -- and the next level starts c bytes further.
+      // (Otherwise they all END here, equal: the general path below writes them out in their order and finishes.)
+      uint64_t k0 = 0;
+      RS_HIP(c, hipMemcpyAsync(&k0, keys, sizeof(k0), hipMemcpyDeviceToHost, s));
+      RS_HIP(c, hipStreamSynchronize(s));
+      if ((k0 & 0xFF) == cbytes) { depth += cbytes; continue; }
+    }
+    // the string ids in sorted order: while the ids are the identity (no compaction yet) the sorted payload is already that
+    const uint32_t* ids_sorted = val;
+    if (cur_ids) { hipLaunchKernelGGL(rss::gather_u32_kernel, grid(m), dim3(rss::kBlock), 0, s, cur_ids, val, mm, ids_sorted_buf); ids_sorted = ids_sorted_buf; }
+    // (positions stay where they are: the subset occupies the same ascending slots of the permutation before and after its sort)
+    hipLaunchKernelGGL(rss::write_back_kernel, grid(m), dim3(rss::kBlock), 0, s, ids_sorted, cur_pos, mm, perm);
+    hipLaunchKernelGGL(rss::heads_open_kernel, grid(m), dim3(rss::kBlock), 0, s, keys, mm, cbytes, head, val_alt /* open */);
+    scan(head, m, scan_a, true);                       // segment numbers (1-based)
+    unsigned blocks = scan(val_alt, m, scan_b, false); // slots of the unresolved
+    uint32_t open_count = 0;
+    RS_HIP(c, hipMemcpyAsync(&open_count, block_sums + blocks, 4, hipMemcpyDeviceToHost, s));
+    RS_HIP(c, hipStreamSynchronize(s));
+    if (open_count == 0) break;
+    uint32_t* next_pos = cur_pos == pos ? pos2 : pos;
+    // (the compacted ids go to `ids`: what it held, this level's ids before the sort, was last read by the gather above)
+    hipLaunchKernelGGL(rss::compact_kernel, grid(m), dim3(rss::kBlock), 0, s, val_alt, scan_b, scan_a, ids_sorted, cur_pos, mm,
+                       ids, next_pos, seg);
+    cur_pos = next_pos;
+    cur_ids = ids;
+    cur_seg = seg;
+    max_seg = m;            // segment numbers are < m
+    m = open_count;
+    depth += cbytes;
+    if (level > (1u << 28)) { restore(); return fail(c, RS_ERR_KERNEL, "string sort did not converge"); }
+  }
+  restore();
+  c->last_string_levels = static_cast<int>(level) + 1;
+  RS_HIP(c, hipGetLastError());
+  if constexpr (sizeof(OFF) == 8) {
+    hipLaunchKernelGGL(rss::widen_kernel, grid(n), dim3(rss::kBlock), 0, s, perm, static_cast<uint32_t>(n), keys);
+    if (prof_strings) { RS_HIP(c, hipEventRecord(c->ev[1], s)); c->ev_count = 2; }   // rs_ctx_get_profile: ms[0] = device time of the string sort
+    if ((rc = to_host(c, h_perm, keys, n * 8, 0)) != RS_OK) return rc;
+  } else {
+    if (prof_strings) { RS_HIP(c, hipEventRecord(c->ev[1], s)); c->ev_count = 2; }
+    if ((rc = to_host(c, h_perm, perm, n * 4, 0)) != RS_OK) return rc;
+  }
+  return finish_host_call(c);
 }
 
 }  // namespace
@@ -1322,97 +1447,13 @@ int rs_digit_histogram_device(rs_ctx* c, const void* d_keys, size_t n, int key_b
 }
 
 int rs_sort_strings(rs_ctx* c, const uint8_t* h_blob, const uint64_t* h_offsets, size_t n, uint64_t* h_perm, int stable) {
-  (void)stable;   // every pass is stable and level 0 starts from the identity: one code path serves both
-  if (!c) return RS_ERR_ARG;
-  if (n > 0 && (!h_offsets || !h_perm)) return fail(c, RS_ERR_ARG, "null offsets/perm pointer");
-  if (n >= 0xFFFFFFFFull) return fail(c, RS_ERR_ARG, "string sort takes fewer than 2^32 - 1 strings");
-  if (n == 0) return RS_OK;
-  if (n == 1) { h_perm[0] = 0; return RS_OK; }
-  const uint64_t total = h_offsets[n];
-  if (total > 0 && !h_blob) return fail(c, RS_ERR_ARG, "null blob pointer");
-  c->fetched[0] = c->fetched[1] = {nullptr, 0};   // nothing left over from a call that failed half-way
-  RS_HIP(c, hipSetDevice(c->device));
-  hipStream_t s = c->stream;
-
-  // carve one device allocation
-  auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
-  const size_t m0 = n;
-  const size_t blocks0 = (m0 + rss::kScanTile - 1) / rss::kScanTile;
-  size_t need = up(total + 8) + up((n + 1) * 8) + 2 * up(m0 * 8) /*keys, keys_alt (also the widened perm)*/ +
-                13 * up(m0 * 4) + up((blocks0 + 2) * 4);
-  int rc;
-  if ((rc = ensure(c, c->strbuf, need)) != RS_OK) return rc;
-  char* p = static_cast<char*>(c->strbuf.p);
-  auto take = [&](size_t b) { char* q = p; p += up(b); return q; };
-  auto* d_blob = reinterpret_cast<uint8_t*>(take(total + 8));
-  auto* d_off = reinterpret_cast<uint64_t*>(take((n + 1) * 8));
-  auto* keys = reinterpret_cast<uint64_t*>(take(m0 * 8));
-  auto* keys_alt = reinterpret_cast<uint64_t*>(take(m0 * 8));
-  uint32_t* u[13];
-  for (auto& q : u) q = reinterpret_cast<uint32_t*>(take(m0 * 4));
-  uint32_t *perm = u[0], *val = u[1], *val_alt = u[2], *seg = u[3], *seg2 = u[4], *seg_alt = u[5], *ids = u[6],
-           *ids2 = u[7], *pos = u[8], *pos2 = u[9], *head = u[10], *scan_a = u[11], *scan_b = u[12];
-  auto* block_sums = reinterpret_cast<uint32_t*>(take((blocks0 + 2) * 4));
-
-  if (total && (rc = to_device(c, d_blob, h_blob, total, 0)) != RS_OK) return rc;
-  if ((rc = to_device(c, d_off, h_offsets, (n + 1) * 8, 1)) != RS_OK) return rc;
-
-  auto grid = [](size_t m) { return dim3(static_cast<unsigned>((m + rss::kBlock - 1) / rss::kBlock)); };
-  auto scan = [&](const uint32_t* in, size_t m, uint32_t* out, bool inclusive) {
-    unsigned blocks = static_cast<unsigned>((m + rss::kScanTile - 1) / rss::kScanTile);
-    hipLaunchKernelGGL(rss::scan_block_sums_kernel, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums);
-    hipLaunchKernelGGL(rss::scan_spine_kernel, dim3(1), dim3(rss::kBlock), 0, s, block_sums, blocks);
-    if (inclusive) hipLaunchKernelGGL(rss::scan_apply_kernel<true>, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums, out);
-    else hipLaunchKernelGGL(rss::scan_apply_kernel<false>, dim3(blocks), dim3(rss::kBlock), 0, s, in, static_cast<uint32_t>(m), block_sums, out);
-    return blocks;
-  };
-
-  const bool prof_strings = c->profiling;
-  if (prof_strings) RS_HIP(c, hipEventRecord(c->ev[0], s));     // the device part: everything between the upload and the download
-  size_t m = n;
-  uint32_t* cur_pos = nullptr;      // level 0: position j is slot j
-  uint32_t* cur_seg = nullptr;      // level 0: one segment
-  size_t max_seg = 0;
-  const bool prof = c->profiling;
-  c->profiling = false;             // the per-kernel event slots belong to single sorts
-  for (uint32_t level = 0;; ++level) {
-    const uint32_t mm = static_cast<uint32_t>(m);
-    hipLaunchKernelGGL(rss::iota_kernel, grid(m), dim3(rss::kBlock), 0, s, val, level == 0 ? ids : nullptr, mm);
-    hipLaunchKernelGGL(rss::chunk_keys_kernel, grid(m), dim3(rss::kBlock), 0, s, d_blob, d_off, ids, nullptr, mm, level, keys);
-    if ((rc = sort_device(c, keys, val, keys_alt, val_alt, m, 8, 4, RS_XF_NONE, 0, 64)) != RS_OK) { c->profiling = prof; return rc; }
-    if (level > 0) {
-      hipLaunchKernelGGL(rss::gather_u32_kernel, grid(m), dim3(rss::kBlock), 0, s, cur_seg, val, mm, seg2);
-      int bits = 1;
-      while (bits < 32 && (size_t(1) << bits) <= max_seg) ++bits;
-      if ((rc = sort_device(c, seg2, val, seg_alt, val_alt, m, 4, 4, RS_XF_NONE, 0, bits)) != RS_OK) { c->profiling = prof; return rc; }
-      hipLaunchKernelGGL(rss::chunk_keys_kernel, grid(m), dim3(rss::kBlock), 0, s, d_blob, d_off, ids, val, mm, level, keys);
-    }
-    // the string ids in sorted order: at level 0 ids is the identity, so the sorted payload is already that
-    const uint32_t* ids_sorted = val;
-    if (level > 0) { hipLaunchKernelGGL(rss::gather_u32_kernel, grid(m), dim3(rss::kBlock), 0, s, ids, val, mm, ids2); ids_sorted = ids2; }
-    hipLaunchKernelGGL(rss::write_back_kernel, grid(m), dim3(rss::kBlock), 0, s, ids_sorted, cur_pos, mm, perm);
-    hipLaunchKernelGGL(rss::heads_open_kernel, grid(m), dim3(rss::kBlock), 0, s, keys, level > 0 ? seg2 : nullptr, mm, head, val_alt /* open */);
-    scan(head, m, scan_a, true);                       // segment numbers (1-based)
-    unsigned blocks = scan(val_alt, m, scan_b, false); // slots of the unresolved
-    uint32_t open_count = 0;
-    RS_HIP(c, hipMemcpyAsync(&open_count, block_sums + blocks, 4, hipMemcpyDeviceToHost, s));
-    RS_HIP(c, hipStreamSynchronize(s));
-    if (open_count == 0) break;
-    uint32_t* next_pos = cur_pos == pos ? pos2 : pos;
-    hipLaunchKernelGGL(rss::compact_kernel, grid(m), dim3(rss::kBlock), 0, s, val_alt, scan_b, scan_a, ids_sorted, cur_pos, mm,
-                       ids, next_pos, seg);
-    cur_pos = next_pos;
-    cur_seg = seg;
-    max_seg = m;            // segment numbers are < m
-    m = open_count;
-    if (level > (1u << 28)) { c->profiling = prof; return fail(c, RS_ERR_KERNEL, "string sort did not converge"); }
-  }
-  c->profiling = prof;
-  RS_HIP(c, hipGetLastError());
-  hipLaunchKernelGGL(rss::widen_kernel, grid(n), dim3(rss::kBlock), 0, s, perm, static_cast<uint32_t>(n), keys);
-  if (prof_strings) { RS_HIP(c, hipEventRecord(c->ev[1], s)); c->ev_count = 2; }   // rs_ctx_get_profile: ms[0] = device time of the string sort
-  if ((rc = to_host(c, h_perm, keys, n * 8, 0)) != RS_OK) return rc;
-  return finish_host_call(c);
+  return sort_strings_impl<uint64_t>(c, h_blob, h_offsets, n, h_perm, stable);
 }
+
+int rs_sort_strings32(rs_ctx* c, const uint8_t* h_blob, const uint32_t* h_offsets, size_t n, uint32_t* h_perm, int stable) {
+  return sort_strings_impl<uint32_t>(c, h_blob, h_offsets, n, h_perm, stable);
+}
+
+int rs_debug_last_string_levels(const rs_ctx* c) { return c ? c->last_string_levels : 0; }   // test / bench hook: MSD levels of the last string sort
 
 }  // extern "C"

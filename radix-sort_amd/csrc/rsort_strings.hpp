@@ -5,20 +5,22 @@
 // from depth 3 on (:559-569, :1241-1255).  The result of all that is std::string::operator<
 // order (unsigned bytes, a proper prefix first), stable on the projected path.
 //
-// On the GPU the same order is produced MSD over 7-BYTE chunks:
-//   chunk key (u64) = the next 7 bytes, big-endian, zero padded, in bits 63..8
-//                     | min(bytes remaining, 7) in bits 7..0
+// On the GPU the same order is produced MSD over CHUNKS of up to 7 bytes:
+//   chunk key (u64) = segment id in the top sbits bits (level 0: none)
+//                     | the next c bytes, big-endian, zero padded, in bits 8c+7..8
+//                     | min(bytes remaining, c) in bits 7..0,          c = min(7, (56 - sbits) / 8)
 // Zero padding alone would make "a" and "a\0" tie; the length byte breaks that tie the right way
 // (shorter first), and it cannot outvote a payload byte because it is the least significant one.
-// Two strings tie on a chunk key only if they agree on those 7 bytes and both continue (length
-// byte 7) or both end at the same place.  Per level:
-//   1. stable LSD pair sort of the unresolved strings by chunk key (the onesweep path, 8 passes),
-//      then -- from level 1 on -- a stable sort by segment id, which regroups the segments of the
-//      previous level (segmented sort without per-segment launches);
-//   2. neighbours that differ in (segment, chunk key) start a new segment; a string is resolved
-//      when its segment has one member or its chunk ended (length byte < 7);
-//   3. the unresolved strings are compacted and go to the next level (7 bytes further).
+// Two strings tie on a chunk key only if they are in the same segment (they tied on every earlier chunk),
+// agree on those c bytes and both continue (length byte c) or both end at the same place.  Per level:
+//   1. ONE stable LSD pair sort of the unresolved strings by chunk key (the onesweep path; passes whose digit
+//      is the same for all keys are not launched) -- the segment id in the key's top bits keeps the segments
+//      of the previous level together and in order, so no second sort regroups them (round 2 ran two);
+//   2. neighbours that differ in the key start a new segment; a string is resolved when its segment has
+//      one member or its chunk ended (length byte < c);
+//   3. the unresolved strings are compacted and go to the next level (c bytes further).
 // Every pass is stable and level 0 starts from the identity, so equal strings keep input order.
+// The chunk's bytes come in through two aligned 8-byte loads and a funnel shift (the blob is padded), not byte by byte.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,14 +30,29 @@ namespace rss {
 constexpr int kChunkBytes = 7;
 constexpr int kBlock = 256;
 
-__device__ __forceinline__ uint64_t chunk_key(const uint8_t* blob, const uint64_t* offsets, uint32_t id, uint32_t level) {
-  const uint64_t begin = offsets[id] + static_cast<uint64_t>(level) * kChunkBytes;
-  const uint64_t end = offsets[id + 1];
+// the 8 bytes at blob + begin, first byte in the TOP byte of the result (the blob is 8-byte aligned and readable 16 bytes past its end)
+__device__ __forceinline__ uint64_t load8_be(const uint8_t* blob, uint64_t begin) {
+  const uint64_t* p = reinterpret_cast<const uint64_t*>(blob + (begin & ~7ull));
+  const uint64_t a = p[0], b = p[1];
+  const unsigned sh = static_cast<unsigned>(begin & 7u) * 8u;
+  const uint64_t v = sh ? (a >> sh) | (b << (64u - sh)) : a;      // byte i (little-endian) = blob[begin + i]
+  return __builtin_bswap64(v);
+}
+
+// chunk key of string `id` at byte `depth`: c bytes (1..7), segment `seg` in the top sbits bits
+template <typename OFF>
+__device__ __forceinline__ uint64_t chunk_key(const uint8_t* blob, const OFF* offsets, uint32_t id, uint64_t depth, unsigned c,
+                                              uint32_t seg, unsigned sbits) {
+  const uint64_t begin = static_cast<uint64_t>(offsets[id]) + depth;
+  const uint64_t end = static_cast<uint64_t>(offsets[id + 1]);
   const uint64_t rem = end > begin ? end - begin : 0;
-  uint64_t k = 0;
-#pragma unroll
-  for (int b = 0; b < kChunkBytes; ++b) k = (k << 8) | (static_cast<uint64_t>(b) < rem ? blob[begin + b] : 0u);
-  return (k << 8) | (rem < kChunkBytes ? rem : kChunkBytes);
+  uint64_t chunk = 0;
+  if (rem) {
+    chunk = load8_be(blob, begin) >> (64u - 8u * c);
+    if (rem < c) chunk &= ~((1ull << (8u * (c - static_cast<unsigned>(rem)))) - 1ull);     // bytes past the end read as 0
+  }
+  const uint64_t k = (chunk << 8) | (rem < c ? rem : c);
+  return sbits ? k | (static_cast<uint64_t>(seg) << (64u - sbits)) : k;
 }
 
 __global__ void iota_kernel(uint32_t* a, uint32_t* b, uint32_t m) {
@@ -43,11 +60,12 @@ __global__ void iota_kernel(uint32_t* a, uint32_t* b, uint32_t m) {
   if (i < m) { a[i] = i; if (b) b[i] = i; }
 }
 
-// keys[j] = chunk key of string ids[src ? src[j] : j]
-__global__ void chunk_keys_kernel(const uint8_t* blob, const uint64_t* offsets, const uint32_t* ids,
-                                  const uint32_t* src, uint32_t m, uint32_t level, uint64_t* keys) {
+// keys[j] = chunk key of string ids[j] (ids == null: string j) in segment seg[j] (seg == null: one segment)
+template <typename OFF>
+__global__ void chunk_keys_kernel(const uint8_t* blob, const OFF* offsets, const uint32_t* ids, const uint32_t* seg, uint32_t m,
+                                  uint64_t depth, unsigned c, unsigned sbits, uint64_t* keys) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < m) keys[j] = chunk_key(blob, offsets, ids[src ? src[j] : j], level);
+  if (j < m) keys[j] = chunk_key<OFF>(blob, offsets, ids ? ids[j] : j, depth, c, seg ? seg[j] : 0u, sbits);
 }
 
 __global__ void gather_u32_kernel(const uint32_t* in, const uint32_t* src, uint32_t m, uint32_t* out) {
@@ -61,31 +79,15 @@ __global__ void write_back_kernel(const uint32_t* ids, const uint32_t* pos, uint
   if (j < m) perm[pos ? pos[j] : j] = ids[j];
 }
 
-// head[j] = 1 if (segment, key) differs from the left neighbour
-__global__ void heads_kernel(const uint64_t* keys, const uint32_t* seg, uint32_t m, uint32_t* head) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < m) head[j] = (j == 0 || keys[j] != keys[j - 1] || (seg && seg[j] != seg[j - 1])) ? 1u : 0u;
-}
-
-// open[j] = 1 if the string must go to the next level: chunk full (it may continue) and not alone
-__global__ void unresolved_kernel(const uint64_t* keys, const uint32_t* head, uint32_t m, uint32_t* open) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < m) {
-    bool alone = head[j] && (j + 1 == m || head[j + 1]);
-    open[j] = ((keys[j] & 0xFF) == kChunkBytes && !alone) ? 1u : 0u;
-  }
-}
-
-// heads_kernel and unresolved_kernel in one launch: a thread looks at its key, its left and its right neighbour
-__global__ void heads_open_kernel(const uint64_t* keys, const uint32_t* seg, uint32_t m, uint32_t* head, uint32_t* open) {
+// (the segment id is part of the key: a differing key is a differing (segment, chunk); c = the level's chunk bytes)
+__global__ void heads_open_kernel(const uint64_t* keys, uint32_t m, unsigned c, uint32_t* head, uint32_t* open) {
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < m) {
     const uint64_t k = keys[j];
-    const uint32_t sg = seg ? seg[j] : 0u;
-    const bool h = j == 0 || k != keys[j - 1] || (seg && sg != seg[j - 1]);
-    const bool next_h = j + 1 == m || k != keys[j + 1] || (seg && sg != seg[j + 1]);
+    const bool h = j == 0 || k != keys[j - 1];
+    const bool next_h = j + 1 == m || k != keys[j + 1];
     head[j] = h ? 1u : 0u;
-    open[j] = ((k & 0xFF) == kChunkBytes && !(h && next_h)) ? 1u : 0u;
+    open[j] = ((k & 0xFF) == c && !(h && next_h)) ? 1u : 0u;
   }
 }
 

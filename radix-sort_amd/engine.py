@@ -165,15 +165,30 @@ class Engine:
         return k, v
 
 
-    def sort_strings_host(self, blob: np.ndarray, offsets: np.ndarray, stable: bool = True):
-        """perm (uint64) such that string perm[i] belongs at position i; string i = blob[offsets[i]:offsets[i+1]]."""
+    def sort_strings_host(self, blob: np.ndarray, offsets: np.ndarray, stable: bool = True, narrow=None, widen=True):
+        """perm (uint64) such that string perm[i] belongs at position i; string i = blob[offsets[i]:offsets[i+1]].
+        narrow: use rs_sort_strings32 (4-byte offsets and permutation; blobs below 4 GiB) -- None = whenever it applies
+        (offsets that are uint32 already are passed as they are; widen=False returns its uint32 permutation as it came)."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        n = np.asarray(offsets).size - 1
+        last = int(np.asarray(offsets)[-1]) if n >= 0 else 0
+        if narrow is None:
+            narrow = last < (1 << 32)
+        if narrow:
+            off32 = np.ascontiguousarray(offsets, dtype=np.uint32)
+            perm32 = np.empty(n, dtype=np.uint32)
+            self._ck(self.lib.rs_sort_strings32(self.h, blob.ctypes.data_as(C.c_void_p), off32.ctypes.data_as(C.c_void_p), n,
+                                                perm32.ctypes.data_as(C.c_void_p), int(stable)))
+            return perm32.astype(np.uint64) if widen else perm32
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-        n = offsets.size - 1
         perm = np.empty(n, dtype=np.uint64)
         self._ck(self.lib.rs_sort_strings(self.h, blob.ctypes.data_as(C.c_void_p), offsets.ctypes.data_as(C.c_void_p), n,
                                           perm.ctypes.data_as(C.c_void_p), int(stable)))
         return perm
+
+    def last_string_levels(self):
+        """MSD levels the last string sort took (diagnostic)."""
+        return int(self.lib.rs_debug_last_string_levels(self.h))
 
 
 def _transform_of(dtype):

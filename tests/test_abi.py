@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "rsort_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rs_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rs_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree():

@@ -66,12 +66,12 @@ int main(int argc, char** argv) {
         auto proj = &Composite::key;
         const std::size_t threads = dev::helperThreads(v.size(), true);
         double t_asc = timed([&] { (void)dev::isAscending(v, proj); });
-        std::optional<dev::PackedStrings> p;
-        double t_pack = timed([&] { p.emplace(dev::packStrings(v, proj, threads)); });
-        dev::Uninitialized<std::uint64_t> perm(v.size());
+        std::optional<dev::PackedStrings<std::uint32_t>> p;      // (10^7 strings of at most 20 bytes: well below 4 GiB)
+        double t_pack = timed([&] { p.emplace(dev::packStrings<std::uint32_t>(v, proj, threads, dev::stringRangeBytes(v, proj, threads))); });
+        dev::Uninitialized<std::uint32_t> perm(v.size());
         rs_ctx* ctx = dev::context();
         rs_ctx_set_host_threads(ctx, static_cast<int>(dev::hostThreads(v.size(), true)));
-        double t_sort = timed([&] { dev::check(ctx, rs_sort_strings(ctx, p->blob.data(), p->offsets.data(), v.size(), perm.data(), 1)); });
+        double t_sort = timed([&] { dev::check(ctx, rs_sort_strings32(ctx, p->blob.data(), p->offsets.data(), v.size(), perm.data(), 1)); });
         double t_apply = timed([&] { dev::applyPermutation(v, perm.data(), threads); });
         double t_free = timed([&] { p.reset(); });
         std::printf("   phases (%zu host threads): order check %.1f  pack %.1f  rs_sort_strings %.1f  apply permutation %.1f  free %.1f ms\n",
