@@ -108,7 +108,9 @@ def bench_single(args):
                         times.append(t1 - t0)
                         prof = eng.profile()          # empty when the order pre-check answered the call
                         hybrid = bool(eng.lib.rs_debug_last_hybrid(eng.h))
-                        if prof and hybrid:           # [histogram, sweep, sweep, group table + group sort, big-group kernel]
+                        if eng.lib.rs_debug_last_distinct(eng.h):
+                            hybrid = "distinct"       # [counting read, read-back + host order of the distinct keys + fill]
+                        if prof and hybrid is True:   # [histogram, sweep, sweep, group table + group sort, big-group kernel]
                             hist_ms.append(prof[0])
                             pass_ms.extend(prof[1:3])
                             group_ms.append(sum(prof[3:]))
@@ -142,6 +144,9 @@ def bench_single(args):
                 two sweeps 2 * 2K, one in-LDS group sort 2K = 7K = 28 bytes."""
                 if not hyb:
                     return {"form": "lsd", "bytes_moved_per_key": b_key}
+                if hyb == "distinct":     # hist_ms = the counting read, pass_ms = the fill (with the host step before it)
+                    return {"form": "few distinct keys: counted in one read (hash table per workgroup), written back as runs",
+                            "bytes_moved_per_key": 2 * kb}
                 return {"form": "hybrid: 2 onesweep passes on the top digits + in-LDS sort of every 16-bit group",
                         "bytes_moved_per_key": 7 * kb, "group_ms": sum(group) / len(group) if group else None}
 
@@ -371,7 +376,7 @@ def main():
     ap.add_argument("--types", default="u32,u64")
     ap.add_argument("--shapes", default="randomized,sorted,reverse_sorted,nearly_sorted,duplicates")
     ap.add_argument("--extra-types", default="i64,f32,f64", help="BASELINE configs[2] rows (fewer repetitions)")
-    ap.add_argument("--extra-shapes", default="randomized,duplicates")
+    ap.add_argument("--extra-shapes", default="randomized,duplicates,nearly_sorted")
     ap.add_argument("--extra-steps", type=int, default=3)
     ap.add_argument("--pairs", default="u32+4,u64+4", help="key type + payload bytes")
     ap.add_argument("--pairs-n", type=int, default=1 << 29)

@@ -115,7 +115,7 @@ struct rs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
-  DevBuf alt_keys, alt_vals, desc, ctrl, strbuf, groups;
+  DevBuf alt_keys, alt_vals, desc, ctrl, strbuf, groups, distinct;
   // ctrl layout: kCtrl* below
   bool rank_by_lds_atomic = false;   // set by the probe in rs_ctx_create
   bool per_xcd_order = false;        // set by the XCC-id probe in rs_ctx_create (and cleared by rs_ctx_set_tile_order)
@@ -135,6 +135,8 @@ struct rs_ctx {
   unsigned group_max_vec = 0;    // test hook: groups of more vectors than this go to the big-group kernel (0 = what the LDS window holds)
   bool last_hybrid = false;      // the last sort_device took the hybrid form
   int last_string_levels = 0;    // MSD levels the last string sort took
+  bool last_distinct = false;    // the last sort_device sorted by counting the few distinct keys (rsd::, rsort_groups.hpp)
+  bool distinct_path = true;     // RSORT_DISTINCT=0 at creation switches that path off (tests, A/B timing)
   bool last_all_equal = false;   // the last sort_device read its digit counts and found every key equal on the sorted bits (nothing launched)
   hipEvent_t ev[kMaxPasses + 4] = {};
   hipEvent_t small_up = nullptr;     // after the last small host-to-device copy through lane 0's bounce buffer (to_device)
@@ -384,12 +386,96 @@ void launch_reverse_k(void* keys, size_t n, hipStream_t s) {
   hipLaunchKernelGGL((rsk::reverse_kernel<K>), dim3(std::max(grid, 1u)), dim3(256), 0, s, static_cast<K*>(keys), static_cast<uint64_t>(n));
 }
 
+// Sort by counting the distinct keys (see the call in sort_device).  *done = 1 when the array has been sorted that way.
+int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t fmask, uint64_t smask, int* done) {
+  *done = 0;
+  hipStream_t s = c->stream;
+  constexpr size_t G = rsd::kGlobalSlots, D = rsd::kDistinctMax;
+  constexpr size_t kOffCnt = G * 8, kOffOnes = kOffCnt + G * 8, kOffUsed = kOffOnes + 8, kOffSorted = kOffUsed + 8,
+                   kOffStarts = kOffSorted + (D + 1) * 8, kBytes = kOffStarts + (D + 2) * 8;
+  int rc;
+  if ((rc = ensure(c, c->distinct, kBytes)) != RS_OK) return rc;
+  char* d = static_cast<char*>(c->distinct.p);
+  rsd::CollectArgs a{};
+  a.keys = keys; a.gkeys = d; a.gcnt = reinterpret_cast<unsigned long long*>(d + kOffCnt);
+  a.ones = reinterpret_cast<unsigned long long*>(d + kOffOnes); a.used = reinterpret_cast<unsigned*>(d + kOffUsed);
+  auto launch = [&](unsigned grid) {
+    if (key_bytes == 4) hipLaunchKernelGGL((rsd::distinct_collect_kernel<uint32_t, 1024>), dim3(grid), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((rsd::distinct_collect_kernel<uint64_t, 1024>), dim3(grid), dim3(1024), 0, s, a);
+  };
+  // 1. the sample: the first 2^18 keys, one workgroup
+  unsigned used[2] = {0, 0};
+  RS_HIP(c, hipMemsetAsync(a.used, 0, 8, s));
+  a.n = std::min<size_t>(n, size_t(1) << 18); a.probe = 1;
+  launch(1);
+  RS_HIP(c, hipMemcpyAsync(used, a.used, 8, hipMemcpyDeviceToHost, s));
+  RS_HIP(c, hipStreamSynchronize(s));
+  if (used[0] > D) return RS_OK;
+  // 2. the whole array
+  int ev = 0;
+  if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+  RS_HIP(c, hipMemsetAsync(d, 0xFF, G * 8, s));
+  RS_HIP(c, hipMemsetAsync(d + kOffCnt, 0, kOffSorted - kOffCnt, s));
+  a.n = n; a.probe = 0;
+  launch(static_cast<unsigned>(c->cus) * 2u);
+  if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+  std::vector<unsigned char> h(kOffSorted);
+  RS_HIP(c, hipMemcpyAsync(h.data(), d, kOffSorted, hipMemcpyDeviceToHost, s));
+  RS_HIP(c, hipStreamSynchronize(s));
+  std::memcpy(used, h.data() + kOffUsed, 8);
+  if (used[1] || used[0] > D) return RS_OK;                 // more distinct keys than the path serves: the usual sort
+  struct Entry { uint64_t order, raw, count; };
+  std::vector<Entry> e;
+  const uint64_t all = key_bytes == 8 ? ~0ull : 0xFFFFFFFFull, sign = 1ull << (key_bytes * 8 - 1);
+  auto forward = [&](uint64_t raw) {                        // xf_forward (rsort_kernels.hpp): the order the keys sort in
+    const uint64_t fill = (raw & sign) ? all : 0;
+    return (raw ^ ((fill & fmask) | smask)) & all;
+  };
+  uint64_t total = 0;
+  for (size_t i = 0; i < G; ++i) {
+    uint64_t raw = 0, cnt = 0;
+    std::memcpy(&raw, h.data() + i * key_bytes, key_bytes);
+    std::memcpy(&cnt, h.data() + kOffCnt + i * 8, 8);
+    if (raw == all) continue;
+    e.push_back({forward(raw), raw, cnt});
+    total += cnt;
+  }
+  uint64_t ones = 0;
+  std::memcpy(&ones, h.data() + kOffOnes, 8);
+  if (ones) { e.push_back({forward(all), all, ones}); total += ones; }
+  if (total != n || e.empty() || e.size() > D) return RS_OK;    // (keys that changed under the count: leave it to the usual sort and its checks)
+  std::sort(e.begin(), e.end(), [](const Entry& x, const Entry& y) { return x.order < y.order; });
+  std::vector<unsigned char> up((D + 1) * 8 + (D + 2) * 8, 0);
+  uint64_t at = 0;
+  for (size_t i = 0; i < e.size(); ++i) {
+    std::memcpy(up.data() + i * key_bytes, &e[i].raw, key_bytes);
+    std::memcpy(up.data() + (D + 1) * 8 + i * 8, &at, 8);
+    at += e[i].count;
+  }
+  std::memcpy(up.data() + (D + 1) * 8 + e.size() * 8, &at, 8);
+  RS_HIP(c, hipMemcpyAsync(d + kOffSorted, up.data(), up.size(), hipMemcpyHostToDevice, s));
+  RS_HIP(c, hipStreamSynchronize(s));                       // (the staging vector goes out of scope)
+  rsd::FillArgs f{};
+  f.out = keys; f.n = n; f.sorted_keys = d + kOffSorted; f.starts = reinterpret_cast<const unsigned long long*>(d + kOffStarts);
+  f.distinct = static_cast<unsigned>(e.size());
+  const unsigned grid = static_cast<unsigned>(std::min<size_t>((n * key_bytes / 16 + 255) / 256, size_t(c->cus) * 16));
+  if (key_bytes == 4) hipLaunchKernelGGL((rsd::fill_runs_kernel<uint32_t, 256>), dim3(std::max(grid, 1u)), dim3(256), 0, s, f);
+  else hipLaunchKernelGGL((rsd::fill_runs_kernel<uint64_t, 256>), dim3(std::max(grid, 1u)), dim3(256), 0, s, f);
+  RS_HIP(c, hipGetLastError());
+  if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+  c->ev_count = c->profiling ? ev : 0;
+  c->last_distinct = true;
+  *done = 1;
+  return RS_OK;
+}
+
 // The device sort proper.  keys/vals are sorted in place; alt_* are same-size scratch.
 int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_vals, size_t n, int key_bytes,
                 int value_bytes, int transform, int begin_bit, int end_bit, const Workspace* ws = nullptr) {
   c->last_unchanged = false;
   c->last_hybrid = false;
   c->last_all_equal = false;
+  c->last_distinct = false;
   if (n < 2) { c->ev_count = 0; return RS_OK; }
   hipStream_t s = c->stream;
   const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
@@ -519,6 +605,17 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       c->ev_count = 0;
       return RS_OK;
     }
+  }
+
+  // Few distinct keys (rsd::, rsort_groups.hpp): large keys-only sorts of whole 4- and 8-byte keys first let one workgroup
+  // count the distinct keys of a sample; when they are few, the whole array is counted the same way and the result is
+  // written as runs -- one read and one write of the keys.  More distinct keys than the table serves anywhere in the array:
+  // the overflow word says so and the sort goes on as usual (the counting read was then wasted: about a tenth of a sort).
+  if (c->distinct_path && !ws && !mid && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 && end_bit == key_bytes * 8 &&
+      (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
+    int done = 0;
+    if ((rc = sort_few_distinct(c, keys, n, key_bytes, fmask, smask, &done)) != RS_OK) return rc;
+    if (done) return RS_OK;
   }
 
   unsigned chain_tiles = 0, chunk_shift = 0, chunk_mul = 0;
@@ -1048,6 +1145,7 @@ int rs_ctx_create(rs_ctx** out, int device) {
     return RS_ERR_HIP;
   }
   c->stream = c->own_stream;
+  if (const char* e = std::getenv("RSORT_DISTINCT")) c->distinct_path = !(e[0] == '0');
   if (const char* e = std::getenv("RSORT_HYBRID")) c->hybrid_mode = std::atoi(e) < 0 ? -1 : std::atoi(e) > 0 ? 1 : 0;
   {
     hipDeviceProp_t prop;
@@ -1150,7 +1248,7 @@ int rs_ctx_destroy(rs_ctx* c) {
   if (!c) return RS_OK;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->alt_keys, &c->alt_vals, &c->desc, &c->ctrl, &c->strbuf, &c->groups})
+  for (DevBuf* b : {&c->alt_keys, &c->alt_vals, &c->desc, &c->ctrl, &c->strbuf, &c->groups, &c->distinct})
     if (b->p) (void)hipFree(b->p);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1208,6 +1306,8 @@ int rs_debug_set_group_limit(rs_ctx* c, unsigned max_vec) {
   return RS_OK;
 }
 int rs_debug_last_hybrid(const rs_ctx* c) { return c && c->last_hybrid ? 1 : 0; }
+int rs_debug_last_distinct(const rs_ctx* c) { return c && c->last_distinct ? 1 : 0; }
+int rs_debug_set_distinct(rs_ctx* c, int on) { if (!c) return RS_ERR_ARG; c->distinct_path = on != 0; return RS_OK; }   // test hook: the few-distinct-keys path on / off
 int rs_debug_desc_local(const rs_ctx* c) { return c && c->desc_local ? 1 : 0; }      // what the chain probe of rs_ctx_create found
 
 int rs_ctx_set_tile_order(rs_ctx* c, int per_xcd) {

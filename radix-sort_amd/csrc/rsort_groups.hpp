@@ -337,12 +337,19 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
 // stable LDS passes of 8 bits, digits that are the same for the whole group skipped), one read and one write of the keys
 // whatever the number of passes.  8-byte keys at N = 2^30: 8 + 2 * 16 + 16 = 56 bytes per key instead of the canonical 136.
 // tile_sort_body for a group of len keys, instantiated for the smallest of 1, 2, 4, 8, 12, 16, ITEMS keys per thread that holds it
-template <typename K, int BLOCK, int ITEMS, typename Smem>
-__device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, unsigned len, K fmo, K smo, int low_bits) {
+// LOW = the low bits the group is sorted on (a constant of the calling kernel: the fix-up's compares fold to one word).
+#ifndef RS_FIX_PREFIX_BITS
+#define RS_FIX_PREFIX_BITS 16     // the passes cover the top 16 of the low bits, the fix-up the rest (0: passes over all the low bits)
+#endif
+template <typename K, int BLOCK, int ITEMS, int LOW, typename Smem>
+__device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, unsigned len, K fmo, K smo) {
   const unsigned per = (len + BLOCK - 1) / BLOCK;        // (workgroup-uniform)
+  // (measured, 16384 keys per group: the fix-up costs what two to three passes cost, so it pays from five passes on -- 8-byte
+  // keys: 48 low bits 41.9 -> 33.3 us per group; the 24 low bits of 4-byte keys are three passes and stay three passes)
+  constexpr int TOP = RS_FIX_PREFIX_BITS > 0 && LOW >= RS_FIX_PREFIX_BITS + 24 ? LOW - RS_FIX_PREFIX_BITS : 0;
   auto run = [&](auto it_tag) {
     constexpr int IT = decltype(it_tag)::value < ITEMS ? decltype(it_tag)::value : ITEMS;
-    tile_sort_body<K, NoVal, BLOCK, IT>(s, gin, gout, static_cast<NoVal*>(nullptr), len, static_cast<K>(0), static_cast<K>(0), fmo, smo, 0, low_bits);
+    tile_sort_body<K, NoVal, BLOCK, IT, TOP>(s, gin, gout, static_cast<NoVal*>(nullptr), len, static_cast<K>(0), static_cast<K>(0), fmo, smo, 0, LOW);
   };
   if (per <= 1) run(std::integral_constant<int, 1>{});
   else if (per <= 2) run(std::integral_constant<int, 2>{});
@@ -370,8 +377,8 @@ __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
     }
     return;
   }
-  group_tile_sort<K, BLOCK, ITEMS>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, len,
-                                   static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), a.low_bits);
+  group_tile_sort<K, BLOCK, ITEMS, (static_cast<int>(sizeof(K)) - 2) * 8>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, len,
+                                                                          static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out));
 }
 
 // Mid-size sorts (at most 256 tiles; SweepArgs::mid_counts has the protocol): after ONE sweep on the top digit, workgroup g
@@ -404,8 +411,8 @@ __global__ __launch_bounds__(BLOCK) void group_sort_mid_kernel(MidArgs a) {
   const unsigned start = static_cast<unsigned>(part[0] + part[1] + part[2] + part[3]);
   const unsigned len = static_cast<unsigned>(a.counts[g]);
   if (len == 0) return;
-  group_tile_sort<K, BLOCK, ITEMS>(s, static_cast<const K*>(a.keys_in) + start, static_cast<K*>(a.keys_out) + start, len,
-                                   static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), a.low_bits);
+  group_tile_sort<K, BLOCK, ITEMS, (static_cast<int>(sizeof(K)) - 1) * 8>(s, static_cast<const K*>(a.keys_in) + start, static_cast<K*>(a.keys_out) + start, len,
+                                                                          static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -572,3 +579,236 @@ __global__ __launch_bounds__(BLOCK) void group_big_kernel(BigArgs a) {
 }
 
 }  // namespace rsk
+
+// ------------------------------------------------------------------------------------------------
+// Few distinct keys (keys only, whole key)
+// ------------------------------------------------------------------------------------------------
+// An array that holds only a handful of different keys -- the reference harness' "duplicates" shape draws every key from 256
+// values (generators.hpp:93-107) -- is sorted once its distinct keys and their counts are known: the output is each key,
+// in order, as often as it occurs.  One read of the keys (counting them in a small hash table per workgroup, merged into
+// a global one) and one write (filling the runs) replace the K passes of the LSD loop: 2 * K bytes per key instead of
+// K * (1 + 2 * K).  Keys only: equal keys are bit-identical, so there is no order among them to keep.
+//   distinct_collect_kernel   probe (a sample, one workgroup: how many distinct keys does it see?) and full count
+//   fill_runs_kernel          writes key i of the sorted distinct keys to positions [starts[i], starts[i + 1])
+// The table holds at most kDistinctMax keys; an array with more sets the overflow word and is sorted the usual way.
+namespace rsd {
+constexpr unsigned kDistinctMax = 1024;          // distinct keys this path serves
+constexpr unsigned kLocalSlots = 4096;           // per-workgroup hash table: open addressing from the first slot of the key's bucket of four on, at most a quarter full
+constexpr unsigned kGlobalSlots = 4096;          // the merged table
+constexpr unsigned kCountCols = 2;               // counters per slot: lane & 1 picks one, so equal keys in one wave queue on two words, not one
+
+struct CollectArgs {
+  const void* keys;
+  uint64_t n;                 // keys to look at
+  void* gkeys;                // [kGlobalSlots] keys of the merged table; empty = all ones
+  unsigned long long* gcnt;   // [kGlobalSlots]
+  unsigned long long* ones;   // occurrences of the key that is all ones (it is the table's "empty" mark)
+  unsigned* used;             // [0] distinct keys in the merged table, [1] overflow (more distinct keys than the path serves)
+  int probe;                  // 1: one workgroup's own table only; used[0] = distinct keys it saw (kDistinctMax + 1: too many)
+};
+
+// Multiplicative hash, top `bits` bits: one 32-bit multiply per key half (a full 64-bit product costs four).
+template <typename K> __device__ __forceinline__ unsigned distinct_hash(K k, unsigned bits) {
+  unsigned h = static_cast<unsigned>(k) * 0x9E3779B1u;
+  if constexpr (sizeof(K) == 8) h ^= static_cast<unsigned>(static_cast<unsigned long long>(k) >> 32) * 0x85EBCA77u + 0x27D4EB2Fu;
+  return h >> (32u - bits);
+}
+constexpr unsigned kLocalBits = 12, kGlobalBits = 12;
+static_assert((1u << kLocalBits) == kLocalSlots && (1u << kGlobalBits) == kGlobalSlots, "table sizes");
+
+template <typename K, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void distinct_collect_kernel(CollectArgs a) {
+  constexpr K kEmpty = static_cast<K>(~static_cast<K>(0));
+  constexpr int VEC = 16 / sizeof(K);
+  __shared__ alignas(16) K lkeys[kLocalSlots];
+  __shared__ unsigned lcnt[kLocalSlots * kCountCols];
+  __shared__ unsigned lused, lover, lones;
+  struct alignas(16) Bucket { K s[4]; };
+  const unsigned tid = threadIdx.x, col = tid & (kCountCols - 1u);
+  for (unsigned i = tid; i < kLocalSlots; i += BLOCK) lkeys[i] = kEmpty;
+  for (unsigned i = tid; i < kLocalSlots * kCountCols; i += BLOCK) lcnt[i] = 0;
+  if (tid == 0) { lused = 0; lover = 0; lones = 0; }
+  __syncthreads();
+
+  // the general case: probe from the first slot of the key's bucket on, claim the first empty one
+  auto add_key = [&](K k) {
+    if (k == kEmpty) { atomicAdd(&lones, 1u); return; }
+    unsigned slot = distinct_hash(k, kLocalBits - 2u) * 4u;
+#pragma nounroll
+    for (unsigned probes = 0; probes < kLocalSlots; ++probes) {
+      K cur = __hip_atomic_load(&lkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (cur == kEmpty) {
+        if (__hip_atomic_load(&lused, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= kDistinctMax) { __hip_atomic_store(&lover, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return; }
+        K expected = kEmpty;
+        if (__hip_atomic_compare_exchange_strong(&lkeys[slot], &expected, k, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          atomicAdd(&lused, 1u);
+          cur = k;
+        } else {
+          cur = expected;
+        }
+      }
+      if (cur == k) { atomicAdd(&lcnt[slot * kCountCols + col], 1u); return; }
+      slot = (slot + 1u) & (kLocalSlots - 1u);
+    }
+    __hip_atomic_store(&lover, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  const K* keys = static_cast<const K*>(a.keys);
+  // 16-byte packs from the first 16-byte boundary on; the keys before it and after the last whole pack one by one (workgroup 0)
+  uint64_t head = ((16u - (reinterpret_cast<uintptr_t>(keys) & 15u)) & 15u) / sizeof(K);
+  if (head > a.n) head = a.n;
+  const uint64_t nvec = (a.n - head) / VEC;
+  struct alignas(16) Pack { K v[VEC]; };
+  const Pack* packs = reinterpret_cast<const Pack*>(keys + head);
+  const uint64_t stride = static_cast<uint64_t>(gridDim.x) * BLOCK;
+  // two packs per turn, each fetched while the other is counted
+  auto count_pack = [&](const Pack& pk) -> bool {
+    // the usual case, straight-line: the key sits in one of the four slots of its bucket -- one 16-byte read per key (two
+    // for 8-byte keys), all the look-ups of the pack in flight together (13 instructions per key: at 2^30 keys the kernel
+    // has about 29 per 4-byte key before it, not the memory, sets the time).  Anything else -- first sight of a key, a
+    // bucket that has overflowed into the next, the all-ones key -- takes the general path.  A read that races with another
+    // wave's insert sees the slot empty or taken, both of which the general path handles.
+    unsigned bucket[VEC];
+    Bucket cur[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) bucket[j] = distinct_hash(pk.v[j], kLocalBits - 2u);
+    __asm__ volatile("" ::: "memory");                     // (the table changes under the loop: read it again every time round)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) cur[j] = *reinterpret_cast<const Bucket*>(&lkeys[bucket[j] * 4u]);
+    const unsigned over = __hip_atomic_load(&lover, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned slow = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      unsigned idx = 4;
+#pragma unroll
+      for (int t = 3; t >= 0; --t) idx = cur[j].s[t] == pk.v[j] ? static_cast<unsigned>(t) : idx;
+      if (idx < 4u && pk.v[j] != kEmpty) atomicAdd(&lcnt[(bucket[j] * 4u + idx) * kCountCols + col], 1u);
+      else slow |= 1u << j;
+    }
+    if (over) return true;                                 // too many distinct keys: nothing more to learn
+    if (slow) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        if ((slow >> j) & 1u) add_key(pk.v[j]);
+    }
+    return false;
+  };
+  uint64_t i = static_cast<uint64_t>(blockIdx.x) * BLOCK + tid;
+  Pack pa{}, pb{};
+  if (i < nvec) pa = packs[i];
+  while (i < nvec) {
+    if (i + stride < nvec) pb = packs[i + stride];
+    if (count_pack(pa)) break;
+    if (i + stride >= nvec) break;
+    if (i + 2 * stride < nvec) pa = packs[i + 2 * stride];
+    if (count_pack(pb)) break;
+    i += 2 * stride;
+  }
+  if (blockIdx.x == 0) {
+    if (tid < head) add_key(keys[tid]);
+    const uint64_t t = head + nvec * VEC + tid;
+    if (t < a.n) add_key(keys[t]);
+  }
+  __syncthreads();
+  if (a.probe) {
+    if (tid == 0) a.used[0] = lover ? kDistinctMax + 1u : lused;
+    return;
+  }
+  if (lover) {                                             // (workgroup-uniform)
+    if (tid == 0) a.used[1] = 1u;
+    return;
+  }
+  if (tid == 0 && lones) atomicAdd(a.ones, static_cast<unsigned long long>(lones));
+  K* gkeys = static_cast<K*>(a.gkeys);
+  for (unsigned i2 = tid; i2 < kLocalSlots; i2 += BLOCK) {
+    const K k = lkeys[i2];
+    if (k == kEmpty) continue;
+    unsigned long long c = 0;
+#pragma unroll
+    for (unsigned j = 0; j < kCountCols; ++j) c += lcnt[i2 * kCountCols + j];
+    unsigned slot = distinct_hash(k, kGlobalBits);
+    bool placed = false;
+    for (unsigned probes = 0; probes < kGlobalSlots && !placed; ++probes) {
+      K cur = __hip_atomic_load(&gkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == kEmpty) {
+        K expected = kEmpty;
+        if (__hip_atomic_compare_exchange_strong(&gkeys[slot], &expected, k, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          if (atomicAdd(&a.used[0], 1u) >= kDistinctMax) a.used[1] = 1u;
+          cur = k;
+        } else {
+          cur = expected;
+        }
+      }
+      if (cur == k) { atomicAdd(&a.gcnt[slot], c); placed = true; }
+      slot = (slot + 1u) & (kGlobalSlots - 1u);
+    }
+    if (!placed) a.used[1] = 1u;
+  }
+}
+
+struct FillArgs {
+  void* out;
+  uint64_t n;
+  const void* sorted_keys;            // [distinct] raw key bits, in output order
+  const unsigned long long* starts;   // [distinct + 1], starts[distinct] = n
+  unsigned distinct;
+};
+
+template <typename K, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void fill_runs_kernel(FillArgs a) {
+  constexpr int VEC = 16 / sizeof(K);
+  __shared__ unsigned long long ls[kDistinctMax + 2];
+  __shared__ K lk[kDistinctMax + 1];
+  const unsigned tid = threadIdx.x;
+  for (unsigned i = tid; i <= a.distinct; i += BLOCK) ls[i] = a.starts[i];
+  for (unsigned i = tid; i < a.distinct; i += BLOCK) lk[i] = static_cast<const K*>(a.sorted_keys)[i];
+  __syncthreads();
+  K* out = static_cast<K*>(a.out);
+  auto run_of = [&](uint64_t p) {                 // the run that holds position p: last i with starts[i] <= p
+    unsigned lo = 0, hi = a.distinct;             // invariant: starts[lo] <= p < starts[hi]
+    while (hi - lo > 1) {
+      const unsigned mid = (lo + hi) >> 1;
+      if (ls[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  uint64_t head = ((16u - (reinterpret_cast<uintptr_t>(out) & 15u)) & 15u) / sizeof(K);
+  if (head > a.n) head = a.n;
+  const uint64_t nvec = (a.n - head) / VEC;
+  struct alignas(16) Pack { K v[VEC]; };
+  Pack* packs = reinterpret_cast<Pack*>(out + head);
+  // every workgroup fills its own contiguous share front to back: the run of a thread's next pack is the run of its
+  // last one or a later one, so one search at the start and a step forward now and then is all the looking-up there is
+  const uint64_t per = (nvec + gridDim.x - 1) / gridDim.x;
+  const uint64_t lo = per * blockIdx.x, hi = lo + per < nvec ? lo + per : nvec;
+  uint64_t i = lo + tid;
+  if (i < hi) {
+    unsigned r = run_of(head + i * VEC);
+    unsigned long long next = ls[r + 1];
+    for (; i < hi; i += BLOCK) {
+      const uint64_t p = head + i * VEC;
+      while (p >= next) next = ls[++r + 1];                // (p < n = starts[distinct]: r stays below distinct)
+      const K kv = lk[r];
+      Pack pk;
+      if (p + VEC <= next) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) pk.v[j] = kv;
+      } else {                                             // a pack that straddles run boundaries
+        unsigned rr = r;
+        unsigned long long nn = next;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          while (p + j >= nn) nn = ls[++rr + 1];           // (empty runs do not exist: every listed key occurs)
+          pk.v[j] = lk[rr];
+        }
+      }
+      packs[i] = pk;
+    }
+  }
+  if (blockIdx.x == 0) {
+    if (tid < head) out[tid] = lk[run_of(tid)];
+    const uint64_t t = head + nvec * VEC + tid;
+    if (t < a.n) out[t] = lk[run_of(t)];
+  }
+}
+}  // namespace rsd

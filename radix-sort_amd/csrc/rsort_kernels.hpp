@@ -1425,7 +1425,15 @@ struct TileSortSmem {
 // ITEMS = keys per thread of THIS call: at most what the shared-memory block was sized for (a kernel that sorts groups of
 // different sizes instantiates the body for several and picks the smallest that holds the group: every phase is a loop
 // over ITEMS rounds whether they hold keys or not).
-template <typename K, typename V, int BLOCK, int ITEMS, typename Smem>
+//
+// TOP (keys only; 0 = off; needs begin_bit == 0 and keys that agree on every bit from end_bit up, as the keys of one group
+// do): sort on the bits [TOP, end_bit) alone, then put the keys that agree on those bits -- they are neighbours now -- in
+// order among themselves by comparing whole keys: every key counts the larger keys of its run before it and the smaller
+// ones behind it, and moves by the difference.  Two passes and the fix-up instead of six or seven passes for the groups of
+// 8-byte keys, whose runs of equal 16-bit prefix are one or two keys long.  A run that reaches more than kFixRunMax
+// places to either side of one of its members calls the fix-up off and the passes run again, over all the bits.
+constexpr unsigned kFixRunMax = 16;
+template <typename K, typename V, int BLOCK, int ITEMS, int TOP = 0, typename Smem>
 __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* gv, unsigned n, K fm_in, K sm_in,
                                                K fm_out, K sm_out, int begin_bit, int end_bit) {
   constexpr int WAVES = BLOCK / kWave;
@@ -1446,7 +1454,16 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
   }
 
   unsigned* wwords = reinterpret_cast<unsigned*>(s.whist[wave]);
-  for (int shift = begin_bit; shift < end_bit; shift += kRadixBits) {
+  constexpr int top_bit = TOP;
+  bool fix = !HAS_VAL && TOP > 0 && begin_bit == 0 && top_bit < end_bit && n > 1;      // (workgroup-uniform)
+  bool staged = false;                                     // the staging area holds the keys in their current order
+  unsigned short moved_to[TOP > 0 ? ITEMS : 1];            // where the fix-up sends each key (else it stays where the passes left it)
+  if constexpr (TOP > 0) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) moved_to[i] = static_cast<unsigned short>(seg + i * kWave);
+  }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+  for (int shift = fix ? top_bit : begin_bit; shift < end_bit; shift += kRadixBits) {
     const int bits = end_bit - shift < kRadixBits ? end_bit - shift : kRadixBits;
 #pragma unroll
     for (int i = 0; i < kRadix / 2 / kWave; ++i) wwords[i * kWave + lane] = 0;
@@ -1504,14 +1521,100 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
         if constexpr (HAS_VAL) val[i] = s.stage_v[idx];
       }
     }
+    staged = true;
     // no barrier: the next pass writes the staging area only behind its own two barriers, and each wave zeroes and
     // fills only its own histogram row before the first of them
+  }
+  if (!fix) break;
+  // the fix-up.  The staging area may not hold the keys at all (every pass skipped: one prefix for the whole tile); it is
+  // only read from here on, and the keys go from the registers straight to their places in the output.
+  if constexpr (TOP > 0) {
+  if (!staged) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+      if (seg + i * kWave < n) s.stage_k[seg + i * kWave] = key[i];
+    __syncthreads();
+    staged = true;
+  }
+  // Round r looks r places to either side.  Rounds 1 and 2 for all the keys of the thread at once, straight-line, the reads
+  // in flight together (a loop per key over its own run costs five counting passes in waits); from round 3 on only
+  // for the few keys whose run reaches that far, and a wave stops when it has none.
+  unsigned alive_l = 0, alive_r = 0;                       // bit i: key i's run may reach further on that side
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i)
+    if (seg + i * kWave < n) { alive_l |= 1u << i; alive_r |= 1u << i; }
+  // (8-byte keys split at bit 32: one 32-bit compare each for "same prefix" and, among keys of one prefix, "larger")
+  constexpr bool kSplitWords = sizeof(K) == 8 && TOP == 32;
+  auto same_prefix = [](K x, K y) {
+    if constexpr (kSplitWords) return static_cast<unsigned>(static_cast<unsigned long long>(x) >> 32) == static_cast<unsigned>(static_cast<unsigned long long>(y) >> 32);
+    else return ((x ^ y) >> top_bit) == 0;
+  };
+  auto low_part = [](K x) {
+    if constexpr (kSplitWords) return static_cast<unsigned>(x);
+    else return x;
+  };
+  auto look_left = [&](int i, unsigned r, K o) {
+    const bool same = ((alive_l >> i) & 1u) && seg + i * kWave >= r && same_prefix(o, key[i]);
+    if (same && low_part(o) > low_part(key[i])) --moved_to[i];       // a larger key before this one comes to stand behind it
+    if (!same) alive_l &= ~(1u << i);
+  };
+  auto look_right = [&](int i, unsigned r, K o) {
+    const bool same = ((alive_r >> i) & 1u) && seg + i * kWave + r < n && same_prefix(o, key[i]);
+    if (same && low_part(o) < low_part(key[i])) ++moved_to[i];       // a smaller key behind this one comes to stand before it
+    if (!same) alive_r &= ~(1u << i);
+  };
+  auto round_all = [&](unsigned r) {
+    constexpr int CH = ITEMS < 8 ? ITEMS : 8;              // (keys in flight per batch: registers)
+#pragma unroll
+    for (int base = 0; base < ITEMS; base += CH) {
+      K other[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (base + c < ITEMS) { const unsigned idx = seg + (base + c) * kWave; other[c] = s.stage_k[idx >= r ? idx - r : 0u]; }
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (base + c < ITEMS) look_left(base + c, r, other[c]);
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (base + c < ITEMS) { const unsigned idx = seg + (base + c) * kWave; other[c] = s.stage_k[idx + r < n ? idx + r : 0u]; }
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+        if (base + c < ITEMS) look_right(base + c, r, other[c]);
+    }
+  };
+  bool too_long = false;
+  round_all(1u);
+  if (__any((alive_l | alive_r) != 0)) round_all(2u);
+  for (unsigned r = 3; __any((alive_l | alive_r) != 0); ++r) {
+    if (r > kFixRunMax) { too_long = true; break; }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const unsigned idx = seg + i * kWave;
+      if (__any((alive_l >> i) & 1u)) look_left(i, r, s.stage_k[((alive_l >> i) & 1u) && idx >= r ? idx - r : 0u]);
+      if (__any((alive_r >> i) & 1u)) look_right(i, r, s.stage_k[((alive_r >> i) & 1u) && idx + r < n ? idx + r : 0u]);
+    }
+  }
+  const bool again = __syncthreads_or(too_long);           // (workgroup-uniform; also the last LDS access of the call)
+  if (again) {                                             // the passes again, over all the bits
+#ifdef RS_FIX_STATS
+    if (tid == 0) atomicAdd(RS_FIX_STATS, 1u);
+#endif
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) moved_to[i] = static_cast<unsigned short>(seg + i * kWave);
+    fix = false;
+    continue;
+  }
+  }
+  break;
   }
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const unsigned idx = seg + i * kWave;
     if (idx < n) {
-      gk[idx] = xf_inverse(key[i], fm_out, sm_out);
+      unsigned to = idx;
+      if constexpr (TOP > 0) to = moved_to[i];
+      gk[to] = xf_inverse(key[i], fm_out, sm_out);
       if constexpr (HAS_VAL) gv[idx] = val[i];
     }
   }

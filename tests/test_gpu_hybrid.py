@@ -36,6 +36,7 @@ def test_hybrid_matches_oracle(engine, oracle, name, shape):
     dt, kb, xf = shapes.KEY_TYPES[name]
     engine.set_precheck(False)
     engine.set_hybrid(1)
+    engine.lib.rs_debug_set_distinct(engine.h, 0)          # (the duplicates shape would otherwise be sorted by counting its 256 values)
     try:
         for n in HYBRID_SIZES:
             v = shapes.generate(name, n, shape)
@@ -43,6 +44,7 @@ def test_hybrid_matches_oracle(engine, oracle, name, shape):
             assert hybrid, "the hybrid form was not taken"
             assert got.tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
     finally:
+        engine.lib.rs_debug_set_distinct(engine.h, 1)
         engine.set_hybrid(-1)
         engine.set_precheck(True)
 
@@ -54,6 +56,7 @@ def test_hybrid_unaligned_and_big_groups(engine, oracle):
     rng = np.random.Generator(np.random.PCG64(23))
     engine.set_precheck(False)
     engine.set_hybrid(1)
+    engine.lib.rs_debug_set_distinct(engine.h, 0)
     try:
         n = 4_400_003
         cases = {
@@ -77,6 +80,33 @@ def test_hybrid_unaligned_and_big_groups(engine, oracle):
                 assert hybrid and got.tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), (name, limit)
     finally:
         engine.lib.rs_debug_set_group_limit(engine.h, 0)
+        engine.lib.rs_debug_set_distinct(engine.h, 1)
+        engine.set_hybrid(-1)
+        engine.set_precheck(True)
+
+
+def test_hybrid_prefix_runs_in_wide_groups(engine):
+    """8-byte keys: each group's 48 low bits are sorted by two passes on their top 16 and a fix-up of the keys that agree on
+    those (tile_sort_body's top_bit).  Groups of thousands of keys (512 top-16 values) whose 16-bit prefixes take few values
+    (runs beyond the fix-up's reach: the passes run again over all the bits), about a key's worth each, or many with few
+    low parts (equal whole keys inside the runs)."""
+    rng = np.random.Generator(np.random.PCG64(31))
+    engine.set_precheck(False)
+    engine.set_hybrid(1)
+    engine.lib.rs_debug_set_distinct(engine.h, 0)
+    try:
+        n = 4_500_001
+        top = (rng.integers(0, 32, n, dtype=np.uint64) << np.uint64(59)) | (rng.integers(0, 16, n, dtype=np.uint64) << np.uint64(48))
+        for prefixes, step, lows in ((4, 0x5501, 1 << 32), (600, 97, 1 << 32), (4000, 13, 1 << 32), (3000, 21, 2), (1 << 16, 1, 1 << 32)):
+            pre = (rng.integers(0, prefixes, n, dtype=np.uint64) * np.uint64(step) & np.uint64(0xFFFF)) << np.uint64(32)
+            low = rng.integers(0, lows, n, dtype=np.uint64)
+            if lows == 2:
+                low = np.where(low == 0, np.uint64(0x01020304), np.uint64(0xF1E2D3C4))      # (every digit takes two values: a constant digit is no sort for the hybrid form)
+            v = top | pre | low
+            got, hybrid = _sort_on_device(engine, v, 0, 1)
+            assert hybrid and got.tobytes() == np.sort(v).tobytes(), (prefixes, lows)
+    finally:
+        engine.lib.rs_debug_set_distinct(engine.h, 1)
         engine.set_hybrid(-1)
         engine.set_precheck(True)
 
@@ -91,7 +121,7 @@ import numpy as np, torch
 import radix_sort_amd as rs
 from radix_sort_amd import shapes
 from cpu_checkers import load_oracle
-orc = load_oracle(); eng = rs.Engine(0); eng.set_precheck(False); eng.set_hybrid(1)
+orc = load_oracle(); eng = rs.Engine(0); eng.set_precheck(False); eng.set_hybrid(1); eng.lib.rs_debug_set_distinct(eng.h, 0)
 for name in ("u32", "i32", "f32", "u64", "f64"):
     dt, kb, xf = shapes.KEY_TYPES[name]
     for shape in shapes.SHAPES:
@@ -137,6 +167,7 @@ def test_hybrid_at_full_size():
             eng.sort_keys_(keys, 1)
             eng.synchronize()
             assert bool(eng.lib.rs_debug_last_hybrid(eng.h)) == (shape != "duplicates"), shape
+            assert bool(eng.lib.rs_debug_last_distinct(eng.h)) == (shape == "duplicates"), shape
             assert int(keys.sum(dtype=torch.int64).item()) == want_sum, shape
             step = 1 << 27
             for lo in range(0, n - 1, step):
@@ -145,3 +176,44 @@ def test_hybrid_at_full_size():
             del keys
     finally:
         eng.close()
+
+
+def test_few_distinct_keys(engine, oracle):
+    """Large keys-only sorts whose keys take few distinct values are sorted by counting them (rsd:: in rsort_groups.hpp: one
+    read, one write): the reference's duplicates shape for every 4- and 8-byte type, one and two values, the most the
+    table serves (1024) and one more (back to the usual sort), a few-valued head in front of random keys (the sample
+    says yes, the full count says no), the key that is all ones (the table's "empty" mark), unaligned buffers."""
+    rng = np.random.Generator(np.random.PCG64(99))
+    engine.set_precheck(False)
+    try:
+        n = 5_000_011
+        for name in ("u32", "i32", "f32", "u64", "i64", "f64"):
+            dt, kb, xf = shapes.KEY_TYPES[name]
+            v = shapes.generate(name, n, "duplicates")
+            for offset in (0, 1):
+                got, _ = _sort_on_device(engine, v, xf, offset)
+                assert engine.lib.rs_debug_last_distinct(engine.h) == 1
+                assert got.tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), (name, offset)
+        for count, expect in ((1, 1), (2, 1), (1024, 1), (1025, 0), (5000, 0)):
+            vals = rng.integers(0, 1 << 64, count, dtype=np.uint64)
+            vals[0] = np.uint64(0xFFFFFFFFFFFFFFFF)                     # all ones: counted beside the table
+            if count >= 2:
+                vals[1] = np.uint64(0)
+            for dtype in (np.uint32, np.uint64):
+                pool = np.unique(vals.astype(dtype))
+                while pool.size < count:                                  # (the narrowing may have merged values)
+                    pool = np.unique(np.concatenate((pool, rng.integers(0, 1 << 32, count - pool.size, dtype=np.uint64).astype(dtype))))
+                v = pool[rng.integers(0, pool.size, n)]
+                v[:pool.size] = pool                                      # every value occurs
+                if count == 1:
+                    v[-1] = dtype(7)                                      # (one descent, or a constant array never reaches the sort engine's passes)
+                got, _ = _sort_on_device(engine, v, 0)
+                assert got.tobytes() == np.sort(v).tobytes(), (count, dtype)
+                if count != 1:
+                    assert engine.lib.rs_debug_last_distinct(engine.h) == expect, (count, dtype)
+        v = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+        v[:400_000] = v[:400_000] & np.uint32(3)                          # the sample sees four values
+        got, _ = _sort_on_device(engine, v, 0)
+        assert engine.lib.rs_debug_last_distinct(engine.h) == 0 and got.tobytes() == np.sort(v).tobytes()
+    finally:
+        engine.set_precheck(True)

@@ -202,6 +202,20 @@ def test_mid_size_sorts_between_other_calls(engine, oracle):
                 engine.sort_keys_ptr(t.data_ptr(), n, v.itemsize, 0)
                 engine.synchronize()
                 assert t.cpu().numpy().tobytes() == np.sort(v).tobytes(), (n, v.dtype)
+        # the groups' sort: two passes on the top 16 of the remaining bits, then the keys that agree on them put in order by
+        # comparison (tile_sort_body's top_bit): prefixes of few values (runs beyond the fix-up's reach: the passes run again),
+        # of many (runs of a few keys, equal whole keys among them), of one
+        for n in (300_000, 1_000_000, 3_000_000):
+            for dt, bits in ((np.uint32, 32), (np.uint64, 64)):
+                top = rng.integers(0, 256, n, dtype=np.uint64) << np.uint64(bits - 8)
+                low_w = bits - 24                                                    # bits below the 16-bit prefix
+                for prefixes, lows in ((4, 1 << low_w), (1, 1 << low_w), (n // 1024, 1 << low_w), (n // 512, 3), (1 << 16, 1 << low_w)):
+                    pre = rng.integers(0, max(prefixes, 1), n, dtype=np.uint64) * np.uint64(max((1 << 16) // max(prefixes, 1), 1)) << np.uint64(low_w)
+                    v = (top | pre | rng.integers(0, lows, n, dtype=np.uint64)).astype(dt)
+                    t = torch.from_numpy(v.view(np.uint8).copy()).cuda()
+                    engine.sort_keys_ptr(t.data_ptr(), n, v.itemsize, 0)
+                    engine.synchronize()
+                    assert t.cpu().numpy().tobytes() == np.sort(v).tobytes(), (n, dt, prefixes, lows)
         # host-buffer calls: pre-check read-back before the histogram, pairs through the same control block
         engine.set_precheck(True)
         a = shapes.generate("u32", 120_000, "sorted", seed=1)
