@@ -1564,8 +1564,14 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
     if (same && low_part(o) < low_part(key[i])) ++moved_to[i];       // a smaller key behind this one comes to stand before it
     if (!same) alive_r &= ~(1u << i);
   };
+  // One round for all the keys of the thread.  Only the LEFT neighbour is read and compared: "key p has a smaller key of its
+  // run r places behind it" is "key p + r has a larger key of its run r places before it", which the thread r lanes further
+  // on (or, past lane 63, the next row of the same thread set) has just worked out -- two cross-lane reads of bit masks
+  // per round instead of a second LDS read and compare per key.  Only the wave's last row has its partners in another wave
+  // and looks to the right itself.
   auto round_all = [&](unsigned r) {
     constexpr int CH = ITEMS < 8 ? ITEMS : 8;              // (keys in flight per batch: registers)
+    unsigned larger_before = 0;                            // bit i: the key r places before key i is of its run and larger
 #pragma unroll
     for (int base = 0; base < ITEMS; base += CH) {
       K other[CH];
@@ -1574,13 +1580,29 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
         if (base + c < ITEMS) { const unsigned idx = seg + (base + c) * kWave; other[c] = s.stage_k[idx >= r ? idx - r : 0u]; }
 #pragma unroll
       for (int c = 0; c < CH; ++c)
-        if (base + c < ITEMS) look_left(base + c, r, other[c]);
+        if (base + c < ITEMS) {
+          const int i = base + c;
+          const bool same = ((alive_l >> i) & 1u) && seg + i * kWave >= r && same_prefix(other[c], key[i]);
+          const bool larger = same && low_part(other[c]) > low_part(key[i]);
+          if (larger) { --moved_to[i]; larger_before |= 1u << i; }
+          if (!same) alive_l &= ~(1u << i);
+        }
+    }
+    // (alive_l now says: the key r places before is of this key's run)
+    const bool wrapped = lane + r >= kWave;                // the partner r places on sits in the thread set's next row
+    unsigned run_on = __shfl(alive_l, static_cast<int>((lane + r) & (kWave - 1)), kWave);
+    unsigned smaller_behind = __shfl(larger_before, static_cast<int>((lane + r) & (kWave - 1)), kWave);
+    if (wrapped) { run_on >>= 1; smaller_behind >>= 1; }   // its bit i + 1 speaks of this thread's key i
+    constexpr unsigned last = 1u << (ITEMS - 1);
+    const unsigned keep = wrapped ? alive_r & last : 0u;   // the last row's partners are in the next wave: looked at below
+    run_on &= alive_r;
+    smaller_behind &= run_on;
 #pragma unroll
-      for (int c = 0; c < CH; ++c)
-        if (base + c < ITEMS) { const unsigned idx = seg + (base + c) * kWave; other[c] = s.stage_k[idx + r < n ? idx + r : 0u]; }
-#pragma unroll
-      for (int c = 0; c < CH; ++c)
-        if (base + c < ITEMS) look_right(base + c, r, other[c]);
+    for (int i = 0; i < ITEMS; ++i) moved_to[i] = static_cast<unsigned short>(moved_to[i] + ((smaller_behind >> i) & 1u));
+    alive_r = (wrapped ? run_on & ~last : run_on) | keep;
+    if (wrapped) {
+      const unsigned idx = seg + (ITEMS - 1) * kWave;
+      look_right(ITEMS - 1, r, s.stage_k[((alive_r >> (ITEMS - 1)) & 1u) && idx + r < n ? idx + r : 0u]);
     }
   };
   bool too_long = false;

@@ -1,4 +1,4 @@
-// read_roofline.hip -- how fast can a kernel READ an array on this GPU?  The yardstick for the digit histogram kernel
+// read_roofline.hip -- how fast can a kernel READ an array on this GPU, and how fast can one COPY it?  The yardstick for the digit histogram kernel
 // (one read of the keys, nothing written): the same 16-byte loads, persistent and one-shot grids, several loads in flight.
 //   hipcc -O3 --offload-arch=gfx950 tools/read_roofline.hip -o tools/read_roofline && tools/read_roofline [MiB]
 #include <hip/hip_runtime.h>
@@ -55,6 +55,31 @@ __global__ __launch_bounds__(BLOCK) void read_range_kernel(const uint4* in, size
   if (acc == 0x12345678u) *sink = acc;
 }
 
+// copy: what a kernel that reads an array once and writes it once reaches (the yardstick for the sweeps and the group sort,
+// whose algorithmic bytes are one read + one write of the keys)
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void copy_kernel(const uint4* in, uint4* out, size_t vecs) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * BLOCK;
+  size_t i = static_cast<size_t>(blockIdx.x) * BLOCK + threadIdx.x;
+  for (; i + (UNROLL - 1) * stride < vecs; i += UNROLL * stride) {
+    uint4 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) v[u] = in[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) out[i + u * stride] = v[u];
+  }
+  for (; i < vecs; i += stride) out[i] = in[i];
+}
+template <int BLOCK, int UNROLL>
+__global__ __launch_bounds__(BLOCK) void copy_slab_kernel(const uint4* in, uint4* out, size_t vecs) {
+  const size_t base = static_cast<size_t>(blockIdx.x) * BLOCK * UNROLL + threadIdx.x;
+  uint4 v[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) if (base + u * BLOCK < vecs) v[u] = in[base + u * BLOCK];
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) if (base + u * BLOCK < vecs) out[base + u * BLOCK] = v[u];
+}
+
 template <typename F> static double time_ms(F&& launch) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   std::vector<float> t;
@@ -86,5 +111,16 @@ int main(int argc, char** argv) {
   report("one slab of 64 KB per workgroup (1024 threads x 4 loads)", time_ms([&] { read_slab_kernel<1024, 4><<<static_cast<unsigned>((vecs + 4095) / 4096), 1024>>>(in, vecs, sink); }));
   report("one slab of 32 KB per workgroup (512 threads x 4 loads)", time_ms([&] { read_slab_kernel<512, 4><<<static_cast<unsigned>((vecs + 2047) / 2048), 512>>>(in, vecs, sink); }));
   report("one slab of 16 KB per workgroup (256 threads x 4 loads)", time_ms([&] { read_slab_kernel<256, 4><<<static_cast<unsigned>((vecs + 1023) / 1024), 256>>>(in, vecs, sink); }));
+  // ---- copies: bytes = read + write ----
+  uint4* out; CK(hipMalloc(&out, bytes));
+  auto report2 = [&](const char* what, double ms) { printf("%-58s %.3f ms  %.2f TB/s (read + write)\n", what, ms, 2.0 * bytes / ms / 1e9); };
+  report2("hipMemcpyAsync device to device", time_ms([&] { CK(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, 0)); }));
+  report2("copy, persistent 512 x 1024 threads, 4 in flight", time_ms([&] { copy_kernel<1024, 4><<<512, 1024>>>(in, out, vecs); }));
+  report2("copy, persistent 1024 x 512 threads, 4 in flight", time_ms([&] { copy_kernel<512, 4><<<1024, 512>>>(in, out, vecs); }));
+  report2("copy, persistent 2048 x 256 threads, 4 in flight", time_ms([&] { copy_kernel<256, 4><<<2048, 256>>>(in, out, vecs); }));
+  report2("copy, persistent 768 x 512 threads, 8 in flight", time_ms([&] { copy_kernel<512, 8><<<768, 512>>>(in, out, vecs); }));
+  report2("copy, one 32 KB slab per workgroup (512 x 4)", time_ms([&] { copy_slab_kernel<512, 4><<<static_cast<unsigned>((vecs + 2047) / 2048), 512>>>(in, out, vecs); }));
+  report2("copy, one 64 KB slab per workgroup (1024 x 4)", time_ms([&] { copy_slab_kernel<1024, 4><<<static_cast<unsigned>((vecs + 4095) / 4096), 1024>>>(in, out, vecs); }));
+  report2("copy, one 16 KB slab per workgroup (256 x 4)", time_ms([&] { copy_slab_kernel<256, 4><<<static_cast<unsigned>((vecs + 1023) / 1024), 256>>>(in, out, vecs); }));
   return 0;
 }

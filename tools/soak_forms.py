@@ -1,0 +1,75 @@
+"""Soak of the round-3 forms of large keys-only sorts -- hybrid (two sweeps + in-LDS group sort, forced on at these sizes),
+few distinct keys, the groups' prefix passes + fix-up and its fall-back, oversize groups -- on one context, random size,
+width, transform and key distribution, every result compared element by element with torch.sort of the same keys.
+python tools/soak_forms.py [seconds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import radix_sort_amd as rs
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.Generator(np.random.PCG64(11))
+eng = rs.Engine(0, stream=torch.cuda.current_stream().cuda_stream)
+eng.set_precheck(False)
+t_end = time.time() + budget
+done = fails = 0
+forms = {"hybrid": 0, "distinct": 0, "lsd": 0}
+
+
+def rand_bits(n, kb):
+    if kb == 4:
+        return torch.randint(-2**31, 2**31, (n,), dtype=torch.int64, device="cuda").to(torch.int32)
+    return (torch.randint(-2**31, 2**31, (n,), dtype=torch.int64, device="cuda") << 32) | torch.randint(0, 2**32, (n,), dtype=torch.int64, device="cuda")
+
+
+while time.time() < t_end:
+    kb = int(rng.choice([4, 8]))
+    xf = int(rng.choice([0, 1, 2]))
+    limit = int(rng.choice([0, 0, 0, 1, 30]))              # groups of more than 4 * limit keys go to the big-group kernel (0: what the window holds)
+    n = int(rng.integers(4_300_000, 8_000_000 if limit else 40_000_000))
+    dt = torch.int32 if kb == 4 else torch.int64
+    bits = kb * 8
+    kind = int(rng.integers(7))
+    keys = rand_bits(n, kb)
+    if kind == 1:                                            # few distinct keys (around the table's limit of 1024, too)
+        pool = rand_bits(int(rng.choice([1, 2, 7, 256, 1000, 1024, 1025, 1500, 5000])), kb)
+        if rng.integers(4) == 0:
+            pool[0] = -1                                      # the all-ones key
+        keys = pool[torch.randint(0, pool.numel(), (n,), device="cuda")]
+    elif kind == 2:                                          # few top-16 values: large groups, some beyond the LDS window
+        tops = int(rng.choice([3, 40, 300, 2000]))
+        top = torch.randint(0, tops, (n,), dtype=torch.int64, device="cuda") * int(rng.integers(1, 65536 // tops + 1))
+        keys = ((keys.to(torch.int64) & ((1 << (bits - 16)) - 1)) | (top << (bits - 16))).to(dt)
+    elif kind == 3 and kb == 8:                              # 16-bit prefixes below the group bits taking few values: the fix-up's long runs
+        pre = torch.randint(0, int(rng.choice([2, 50, 700, 5000])), (n,), dtype=torch.int64, device="cuda") * int(rng.integers(1, 13))
+        keys = (keys & ~(0xFFFF << 32)) | ((pre & 0xFFFF) << 32)
+    elif kind == 4:                                          # low bits of few values (equal whole keys inside the runs)
+        keys = keys & ~int((1 << int(rng.integers(8, bits - 16))) - 1 - 5)
+    elif kind == 5:                                          # nearly sorted
+        keys = torch.sort(keys).values
+        m = n // 40
+        a = torch.randint(0, n, (m,), device="cuda"); b = torch.randint(0, n, (m,), device="cuda")
+        tmp = keys[a].clone(); keys[a] = keys[b]; keys[b] = tmp
+    hybrid = int(rng.choice([-1, 1, 1]))
+    eng.set_hybrid(hybrid)
+    eng.lib.rs_debug_set_group_limit(eng.h, limit)
+    sign = -(1 << (bits - 1))
+    src = keys.clone()
+    torch.cuda.synchronize()
+    eng.sort_keys_(keys, xf)
+    eng.synchronize()
+    forms["hybrid" if eng.lib.rs_debug_last_hybrid(eng.h) else "distinct" if eng.lib.rs_debug_last_distinct(eng.h) else "lsd"] += 1
+    order = (lambda k: k if xf == 1 else (k ^ sign if xf == 0 else torch.where(k < 0, ~k ^ sign, k)))
+    want = torch.sort(order(src)).values
+    ok = bool((order(keys) == want).all().item())
+    done += 1
+    if not ok:
+        fails += 1
+        print("FAIL", dict(kb=kb, xf=xf, n=n, kind=kind, hybrid=hybrid, limit=limit), flush=True)
+    if done % 20 == 0:
+        print(f"{done} sorts, {fails} failures, forms {forms}", flush=True)
+    del keys, src, want
+eng.lib.rs_debug_set_group_limit(eng.h, 0)
+print(f"soak_forms: {done} sorts in {budget:.0f} s, failures: {fails}, forms {forms}")
+sys.exit(1 if fails else 0)
