@@ -205,7 +205,8 @@ def bench_pairs(eng, torch, dev, spec, args):
     alt_k, alt_v = torch.empty_like(keys), torch.empty_like(vals)
     iota = torch.arange(n, dtype=vdt, device=dev)
     eng.set_precheck(True)
-    times, pass_ms = [], []
+    times, pass_ms, group_ms = [], [], []
+    hybrid = False
     for it in range(1 + args.extra_steps):
         keys.copy_(src)
         vals.copy_(iota)
@@ -216,7 +217,13 @@ def bench_pairs(eng, torch, dev, spec, args):
         t1 = time.perf_counter()
         if it >= 1:
             times.append(t1 - t0)
-            pass_ms.extend(eng.profile()[1:])
+            prof = eng.profile()
+            hybrid = bool(eng.lib.rs_debug_last_hybrid(eng.h))
+            if hybrid:                                # [histogram, sweep, sweep, group table + group sort]
+                pass_ms.extend(prof[1:3])
+                group_ms.append(sum(prof[3:]))
+            else:
+                pass_ms.extend(prof[1:])
     del alt_k, alt_v, iota
     sign = -(1 << 31) if kb == 4 else -(1 << 63)
     okey = keys if xf == 1 else (keys ^ sign if xf == 0 else torch.where(keys < 0, ~keys ^ sign, keys))
@@ -230,7 +237,10 @@ def bench_pairs(eng, torch, dev, spec, args):
     b_key = algorithmic_bytes_per_key(kb, vb)
     return {"type": name, "value_bytes": vb, "shape": "randomized", "n": n, "ms": sec * 1e3, "gkeys_s": n / sec / 1e9,
             "bytes_per_key": b_key, "hbm_frac": n * b_key / sec / 1e9 / HBM_PEAK_GBS,
+            "form": "hybrid: 2 onesweep passes on the top digits + stable in-LDS sort of every 16-bit group, payload beside the keys" if hybrid else "lsd",
+            "bytes_moved_per_key": kb + 3 * 2 * (kb + vb) if hybrid else b_key,
             "pass_ms": sum(pass_ms) / len(pass_ms) if pass_ms else None,
+            "group_ms": sum(group_ms) / len(group_ms) if group_ms else None,
             "sorted": ok_sorted, "stable": ok_stable, "checksum": ok_perm}
 
 

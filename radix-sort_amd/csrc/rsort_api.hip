@@ -101,6 +101,8 @@ constexpr size_t kWideGroupCap = size_t(kWideGroupBlock) * kWideGroupItems;
 // mid-size sorts of 4-byte keys: groups of equal top byte, whole keys in LDS (rsk::group_sort_mid_kernel), 1024 x 20 keys = 80 KB
 constexpr int kMidGroupBlock = 1024;
 constexpr int kMidGroupItems = 20;
+constexpr int kWidePairGroupItems = 12;   // 8-byte keys with a 4-byte payload: 1024 x 12 = 12288 pairs = 144 KB
+constexpr size_t kWidePairGroupCap = size_t(1024) * kWidePairGroupItems;
 constexpr unsigned kGroupCount = 65536;
 constexpr size_t kGroupsBytes = (size_t(kGroupCount) + 1 + kGroupCount + 1) * sizeof(unsigned);   // start table + list of oversize groups
 
@@ -471,7 +473,7 @@ int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t f
 
 // The device sort proper.  keys/vals are sorted in place; alt_* are same-size scratch.
 int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_vals, size_t n, int key_bytes,
-                int value_bytes, int transform, int begin_bit, int end_bit, const Workspace* ws = nullptr) {
+                int value_bytes, int transform, int begin_bit, int end_bit, const Workspace* ws = nullptr, bool forward_done = false) {
   c->last_unchanged = false;
   c->last_hybrid = false;
   c->last_all_equal = false;
@@ -508,13 +510,16 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   const uint64_t all = key_bytes == 8 ? ~0ull : ((1ull << (key_bytes * 8)) - 1ull);
   const uint64_t fmask = transform == RS_XF_IEEE ? all : 0;
   const uint64_t smask = transform == RS_XF_NONE ? 0 : sign;
+  // forward_done: the keys are in their transformed form already (the pair form of the hybrid sort hands an array back to
+  // the plain loop after its two sweeps, below): nothing is applied as they are read, the inverse still as they are stored
+  const uint64_t fmask_rd = forward_done ? 0 : fmask, smask_rd = forward_done ? 0 : smask;
 
   // Small inputs (at most one tile): one launch of one workgroup does the whole sort in LDS -- no histogram, no
   // descriptors, no pre-check and no host synchronisation (the reference's own small-input shortcut is the insertion
   // sort at n <= 100, radix_sort.hpp:372-392; the result of either is the one stable ascending order).
   // RSORT_SMALL=0 (tests, A/B timing) sends small inputs down the general path instead.
   static const bool small_path = [] { const char* e = std::getenv("RSORT_SMALL"); return !(e && e[0] == '0'); }();
-  if (small_path && tiles == 1 && c->rank_by_lds_atomic) {
+  if (small_path && tiles == 1 && c->rank_by_lds_atomic && !forward_done) {
     int ev = 0;
     if (c->profiling) { RS_HIP(c, hipEventRecord(c->ev[ev++], s)); RS_HIP(c, hipEventRecord(c->ev[ev++], s)); }
     rsk::SmallArgs sa{};
@@ -569,9 +574,9 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // (a stable sort of ordered input is the identity); descending, whole key, no payload -> reverse in place.
   // Not for mid-size device-resident sorts: there the two launches and the read-back cost as much as the sort
   // (the host-buffer entry points, which wait for the device anyway and save a download when the input is in order, ask for it).
-  if (c->precheck && !ws && (!mid || c->host_call)) {
+  if (c->precheck && !ws && (!mid || c->host_call) && !forward_done) {
     rsk::OrderArgs o{};
-    o.keys = keys; o.flags = error_flag + 8; o.n = n; o.fmask = fmask; o.smask = smask;
+    o.keys = keys; o.flags = error_flag + 8; o.n = n; o.fmask = fmask_rd; o.smask = smask_rd;
     o.begin_bit = begin_bit; o.bits = end_bit - begin_bit;
     RS_HIP(c, hipMemsetAsync(o.flags, 0, sizeof(unsigned), s));
     // A one-workgroup probe over the head of the array first: on unordered input it sets both flags and the
@@ -668,7 +673,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   auto* chain_hist = reinterpret_cast<unsigned long long*>(ctrl + kCtrlChainHist);
   auto* next_cnt = reinterpret_cast<unsigned long long*>(ctrl + kCtrlNextCnt);
   rsk::HistArgs h{};
-  h.keys = keys; h.ghist = ghist; h.n = n; h.fmask = fmask; h.smask = smask;
+  h.keys = keys; h.ghist = ghist; h.n = n; h.fmask = fmask_rd; h.smask = smask_rd;
   h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
   h.chain_hist = chain ? chain_hist : nullptr;
   h.chain_keys = chain ? static_cast<uint64_t>(chain_tiles) * tile_keys(key_bytes, value_bytes, true) : 0;
@@ -746,8 +751,12 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   const int hybrid_env = c->hybrid_mode;
   bool hybrid = false;
   const int top_lo = key_bytes - 2, top_hi = key_bytes - 1;          // the two swept digits
-  const size_t group_cap = key_bytes == 4 ? kGroupCap : kWideGroupCap;
-  if (hybrid_env != 0 && !ws && !mid && !wide && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
+  // Pair form (8-byte keys, 4-byte payload; stable): the same two sweeps, the wide group kernel with the payload beside the
+  // keys and a smaller window; a group beyond it sends the array -- as the sweeps left it: a stable rearrangement of the
+  // input, keys transformed -- through the plain loop instead (there is no big-group kernel for pairs).
+  const bool pair_form = value_bytes == 4 && key_bytes == 8 && vals != nullptr;
+  const size_t group_cap = pair_form ? kWidePairGroupCap : key_bytes == 4 ? kGroupCap : kWideGroupCap;
+  if (hybrid_env != 0 && !ws && !mid && !wide && !forward_done && (value_bytes == 0 || pair_form) && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
       end_bit == key_bytes * 8 && n_live == key_bytes && n < (size_t(1) << 32) && c->rank_by_lds_atomic &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
     if (hybrid_env == 1) {
@@ -772,7 +781,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // window.  Whether they do is only known on the device and a mid-size sort does not wait for it, so the kernels of both
   // forms are queued and decide for themselves (rsk::SweepArgs::mid_counts): a sort that takes the short form pays K - 1
   // launches that leave at once; one that cannot (keys that share their top byte: small integers) runs the LSD loop as before.
-  const bool mid_short = mid && in_tile_scan && !ws && c->hybrid_mode != 0 && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) &&
+  const bool mid_short = mid && in_tile_scan && !ws && !forward_done && c->hybrid_mode != 0 && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) &&
                          begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic && n_live == key_bytes;
   const unsigned mid_cap = key_bytes == 4 ? kMidGroupBlock * kMidGroupItems : static_cast<unsigned>(kWideGroupCap);
 
@@ -789,7 +798,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.desc = desc; a.ticket = tickets + p * rsk::kTicketWords; a.gbase = gbase + p * rsk::kRadix; a.error_flag = error_flag;
     a.counts = in_tile_scan ? ghist + p * rsk::kRadix : nullptr;
     a.n = n;
-    a.fmask_in = done == 0 ? fmask : 0; a.smask_in = done == 0 ? smask : 0;                    // first launched pass
+    a.fmask_in = done == 0 ? fmask_rd : 0; a.smask_in = done == 0 ? smask_rd : 0;              // first launched pass
     const bool stores_result = done == n_live - 1 && !hybrid;                                  // last launched pass (the hybrid form's group kernel stores the result)
     a.fmask_out = stores_result ? fmask : 0; a.smask_out = stores_result ? smask : 0;
     a.shift = begin_bit + p * rsk::kRadixBits;
@@ -814,7 +823,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       a.mid_cap = mid_cap;
       a.mid_role = p == top_hi ? 2 : 1;
       a.mid_keys_in = keys; a.mid_keys_out = alt_keys;            // the short form's only sweep: caller's keys -> alternate buffer
-      a.mid_fmask_in = fmask; a.mid_smask_in = smask;
+      a.mid_fmask_in = fmask_rd; a.mid_smask_in = smask_rd;
     }
     launch_sweep_k(a, launch);
     if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
@@ -863,10 +872,31 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
+    } else if (pair_form) {
+      hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
+      ga.vals = vals;
+      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWidePairGroupCap) : static_cast<unsigned>(kWidePairGroupCap);
+      // the largest group, before anything is sorted: big_list[0] doubles as the word the maximum is gathered in
+      hipLaunchKernelGGL(rsk::group_max_kernel, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, static_cast<const unsigned*>(start), big_list);
+      unsigned largest = 0;
+      RS_HIP(c, hipMemcpyAsync(&largest, big_list, sizeof(largest), hipMemcpyDeviceToHost, s));
+      RS_HIP(c, hipStreamSynchronize(s));
+      if (largest > ga.max_vec) {
+        c->last_hybrid = false;
+        RS_HIP(c, hipGetLastError());
+        const int keep = c->hybrid_mode;
+        c->hybrid_mode = 0;
+        rc = sort_device(c, keys, vals, alt_keys, alt_vals, n, key_bytes, value_bytes, transform, begin_bit, end_bit, ws, true);
+        c->hybrid_mode = keep;
+        return rc;
+      }
+      RS_HIP(c, hipMemsetAsync(big_list, 0, sizeof(unsigned), s));
+      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, uint32_t, kWideGroupBlock, kWidePairGroupItems>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
+      if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     } else {
       hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
       ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWideGroupCap) : static_cast<unsigned>(kWideGroupCap);   // (keys, for this kernel)
-      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, kWideGroupBlock, kWideGroupItems>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
+      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint64_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     }

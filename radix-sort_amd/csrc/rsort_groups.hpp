@@ -28,6 +28,7 @@ namespace rsk {
 
 struct GroupArgs {
   void* keys;                  // grouped by the bits above low_bits; each group is sorted in place
+  void* vals;                  // payload that moves with the keys (pair form of the wide kernel only), else null
   const unsigned* start;       // [groups + 1] first element of each group; start[groups] = n
   unsigned groups;
   int low_bits;                // bits still to sort, 1..16 (values are staged as 16-bit words)
@@ -341,15 +342,15 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
 #ifndef RS_FIX_PREFIX_BITS
 #define RS_FIX_PREFIX_BITS 16     // the passes cover the top 16 of the low bits, the fix-up the rest (0: passes over all the low bits)
 #endif
-template <typename K, int BLOCK, int ITEMS, int LOW, typename Smem>
-__device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, unsigned len, K fmo, K smo) {
+template <typename K, typename V, int BLOCK, int ITEMS, int LOW, typename Smem>
+__device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, V* gv, unsigned len, K fmo, K smo) {
   const unsigned per = (len + BLOCK - 1) / BLOCK;        // (workgroup-uniform)
-  // (measured, 16384 keys per group: the fix-up costs what two to three passes cost, so it pays from five passes on -- 8-byte
-  // keys: 48 low bits 41.9 -> 33.3 us per group; the 24 low bits of 4-byte keys are three passes and stay three passes)
+  // (measured, 16384 keys per group: the fix-up costs what one and a half passes cost, so it pays from five passes on -- 8-byte
+  // keys: 48 low bits 41.9 -> 29.2 us per group; the 24 low bits of 4-byte keys are three passes and stay three passes)
   constexpr int TOP = RS_FIX_PREFIX_BITS > 0 && LOW >= RS_FIX_PREFIX_BITS + 24 ? LOW - RS_FIX_PREFIX_BITS : 0;
   auto run = [&](auto it_tag) {
     constexpr int IT = decltype(it_tag)::value < ITEMS ? decltype(it_tag)::value : ITEMS;
-    tile_sort_body<K, NoVal, BLOCK, IT, TOP>(s, gin, gout, static_cast<NoVal*>(nullptr), len, static_cast<K>(0), static_cast<K>(0), fmo, smo, 0, LOW);
+    tile_sort_body<K, V, BLOCK, IT, TOP>(s, gin, gout, gv, len, static_cast<K>(0), static_cast<K>(0), fmo, smo, 0, LOW);
   };
   if (per <= 1) run(std::integral_constant<int, 1>{});
   else if (per <= 2) run(std::integral_constant<int, 2>{});
@@ -360,9 +361,13 @@ __device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, 
   else run(std::integral_constant<int, ITEMS>{});
 }
 
-template <typename K, int BLOCK, int ITEMS>
+// V = NoVal: keys only.  V = a 4-byte payload (a.vals): the stable pair form -- every pass and the fix-up keep equal keys in
+// their order, the payload rides through the staging area beside its key; groups beyond the (smaller) window are only
+// counted in big_list[0] and the host sorts the whole array again, every pass (the big-group kernel is keys only).
+template <typename K, typename V, int BLOCK, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
-  __shared__ TileSortSmem<K, NoVal, BLOCK, ITEMS> s;
+  __shared__ TileSortSmem<K, V, BLOCK, ITEMS> s;
+  constexpr bool HAS_VAL = !__is_same(V, NoVal);
   const unsigned g = blockIdx.x;
   const unsigned start = a.start[g], end = a.start[g + 1];
   if (!group_range_ok(start, end, a.n, a.error_flag)) return;
@@ -373,12 +378,24 @@ __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
   if (len > a.max_vec) {          // (here max_vec counts keys) workgroup-uniform: left to group_big_kernel
     if (threadIdx.x == 0) {
       const unsigned slot = atomicAdd(&a.big_list[0], 1u);
-      if (slot < a.big_cap) a.big_list[1 + slot] = g;
+      if (!HAS_VAL && slot < a.big_cap) a.big_list[1 + slot] = g;
     }
     return;
   }
-  group_tile_sort<K, BLOCK, ITEMS, (static_cast<int>(sizeof(K)) - 2) * 8>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, len,
-                                                                          static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out));
+  V* gv = nullptr;
+  if constexpr (HAS_VAL) gv = static_cast<V*>(a.vals) + start;
+  group_tile_sort<K, V, BLOCK, ITEMS, (static_cast<int>(sizeof(K)) - 2) * 8>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, gv, len,
+                                                                             static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out));
+}
+
+// The largest group of a start table (pair form: asked before anything is sorted).  *out must be zero.
+__global__ __launch_bounds__(kRadix) void group_max_kernel(const unsigned* start, unsigned* out) {
+  const unsigned g = blockIdx.x * kRadix + threadIdx.x;
+  const unsigned lo = start[g], hi = start[g + 1];
+  unsigned len = hi >= lo ? hi - lo : 0xFFFFFFFFu;       // (an inconsistent table: larger than any window)
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) len = max(len, static_cast<unsigned>(__shfl_down(len, off, kWave)));
+  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, len);
 }
 
 // Mid-size sorts (at most 256 tiles; SweepArgs::mid_counts has the protocol): after ONE sweep on the top digit, workgroup g
@@ -411,8 +428,8 @@ __global__ __launch_bounds__(BLOCK) void group_sort_mid_kernel(MidArgs a) {
   const unsigned start = static_cast<unsigned>(part[0] + part[1] + part[2] + part[3]);
   const unsigned len = static_cast<unsigned>(a.counts[g]);
   if (len == 0) return;
-  group_tile_sort<K, BLOCK, ITEMS, (static_cast<int>(sizeof(K)) - 1) * 8>(s, static_cast<const K*>(a.keys_in) + start, static_cast<K*>(a.keys_out) + start, len,
-                                                                          static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out));
+  group_tile_sort<K, NoVal, BLOCK, ITEMS, (static_cast<int>(sizeof(K)) - 1) * 8>(s, static_cast<const K*>(a.keys_in) + start, static_cast<K*>(a.keys_out) + start,
+                                                                                 static_cast<NoVal*>(nullptr), len, static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1426,8 +1426,8 @@ struct TileSortSmem {
 // different sizes instantiates the body for several and picks the smallest that holds the group: every phase is a loop
 // over ITEMS rounds whether they hold keys or not).
 //
-// TOP (keys only; 0 = off; needs begin_bit == 0 and keys that agree on every bit from end_bit up, as the keys of one group
-// do): sort on the bits [TOP, end_bit) alone, then put the keys that agree on those bits -- they are neighbours now -- in
+// TOP (0 = off; needs begin_bit == 0 and keys that agree on every bit from end_bit up, as the keys of one group do; stable,
+// so it serves pairs too: equal keys are never counted as larger or smaller and keep their places): sort on the bits [TOP, end_bit) alone, then put the keys that agree on those bits -- they are neighbours now -- in
 // order among themselves by comparing whole keys: every key counts the larger keys of its run before it and the smaller
 // ones behind it, and moves by the difference.  Two passes and the fix-up instead of six or seven passes for the groups of
 // 8-byte keys, whose runs of equal 16-bit prefix are one or two keys long.  A run that reaches more than kFixRunMax
@@ -1455,7 +1455,7 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
 
   unsigned* wwords = reinterpret_cast<unsigned*>(s.whist[wave]);
   constexpr int top_bit = TOP;
-  bool fix = !HAS_VAL && TOP > 0 && begin_bit == 0 && top_bit < end_bit && n > 1;      // (workgroup-uniform)
+  bool fix = TOP > 0 && begin_bit == 0 && top_bit < end_bit && n > 1;      // (workgroup-uniform)
   bool staged = false;                                     // the staging area holds the keys in their current order
   unsigned short moved_to[TOP > 0 ? ITEMS : 1];            // where the fix-up sends each key (else it stays where the passes left it)
   if constexpr (TOP > 0) {
@@ -1637,13 +1637,20 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const unsigned idx = seg + i * kWave;
-    if (idx < n && moved_to[i] != idx) s.stage_k[moved_to[i]] = key[i];
+    if (idx < n && moved_to[i] != idx) {
+      s.stage_k[moved_to[i]] = key[i];
+      if constexpr (HAS_VAL) s.stage_v[moved_to[i]] = val[i];
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const unsigned idx = seg + i * kWave;
-    if (idx < n && moved_to[i] != idx) { key[i] = s.stage_k[idx]; moved_to[i] = static_cast<unsigned short>(idx); }
+    if (idx < n && moved_to[i] != idx) {
+      key[i] = s.stage_k[idx];
+      if constexpr (HAS_VAL) val[i] = s.stage_v[idx];
+      moved_to[i] = static_cast<unsigned short>(idx);
+    }
   }
   __syncthreads();                                         // (the caller may start another call on this staging area)
 #endif
@@ -1657,7 +1664,7 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
       unsigned to = idx;
       if constexpr (TOP > 0) to = moved_to[i];
       gk[to] = xf_inverse(key[i], fm_out, sm_out);
-      if constexpr (HAS_VAL) gv[idx] = val[i];
+      if constexpr (HAS_VAL) gv[to] = val[i];
     }
   }
 }

@@ -111,6 +111,83 @@ def test_hybrid_prefix_runs_in_wide_groups(engine):
         engine.set_precheck(True)
 
 
+def _sort_pairs_on_device(engine, v, xf, offset=0):
+    """(v, 0..n-1) through rs_sort_pairs_device, 4-byte payload: (sorted keys, payload = the stable permutation, took the hybrid form)."""
+    import torch
+    kb = v.itemsize
+    buf = torch.empty(v.size * kb + 64, dtype=torch.uint8, device="cuda")
+    kview = buf[offset * kb: offset * kb + v.size * kb]
+    kview.copy_(torch.from_numpy(v.view(np.uint8).copy()))
+    vals = torch.arange(v.size, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    engine.sort_pairs_ptr(kview.data_ptr(), vals.data_ptr(), v.size, kb, 4, xf)
+    engine.synchronize()
+    took_hybrid = bool(engine.lib.rs_debug_last_hybrid(engine.h))
+    return kview.cpu().numpy().view(v.dtype), vals.cpu().numpy().astype(np.uint64), took_hybrid
+
+
+@pytest.mark.parametrize("name", ["u64", "i64", "f64"])
+def test_hybrid_pair_form_matches_oracle(engine, oracle, name):
+    """Stable pairs of 8-byte keys and a 4-byte payload in the hybrid form (two sweeps, then every group of equal top 16 bits
+    sorted in LDS with the payload beside the keys): keys and permutation against the oracle's stable pair sort, every shape.
+    Shapes whose groups do not fit the window (256 values: 16 K pairs per group) are handed back to the plain loop after the
+    sweeps -- same result, and the library says it did not take the hybrid form."""
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    engine.set_precheck(False)
+    engine.set_hybrid(1)
+    try:
+        for n in (4_300_001, (1 << 23) + 7):
+            for shape in shapes.SHAPES:
+                v = shapes.generate(name, n, shape)
+                for offset in (0, 1):
+                    keys, perm, hybrid = _sort_pairs_on_device(engine, v, xf, offset)
+                    wk, wp = oracle.sort_pairs(v, xf, mt=True)
+                    assert keys.tobytes() == wk.tobytes() and np.array_equal(perm, wp), (name, shape, n, offset)
+                    # (float ramps: a quarter of the keys share their top nine bits -- groups far beyond the window, the plain loop)
+                    assert hybrid == (shape != "duplicates" and (name != "f64" or shape == "randomized")), (name, shape, n)
+    finally:
+        engine.set_hybrid(-1)
+        engine.set_precheck(True)
+
+
+def test_hybrid_pair_form_prefix_runs_and_windows(engine):
+    """The pair form's fix-up keeps equal keys in their order and moves the payload with its key: 16-bit prefixes of few values
+    (runs beyond its reach: every pass again), of many with few low parts (equal whole keys inside the runs), groups at and just
+    beyond the window (12288 pairs), a window forced small (everything handed back to the plain loop)."""
+    rng = np.random.Generator(np.random.PCG64(37))
+    engine.set_precheck(False)
+    engine.set_hybrid(1)
+    try:
+        n = 4_500_001
+        top = (rng.integers(0, 32, n, dtype=np.uint64) << np.uint64(59)) | (rng.integers(0, 16, n, dtype=np.uint64) << np.uint64(48))
+        for prefixes, step, lows in ((4, 0x5501, 1 << 32), (600, 97, 1 << 32), (3000, 21, 2), (1 << 16, 1, 1 << 32)):
+            pre = (rng.integers(0, prefixes, n, dtype=np.uint64) * np.uint64(step) & np.uint64(0xFFFF)) << np.uint64(32)
+            low = rng.integers(0, lows, n, dtype=np.uint64)
+            if lows == 2:
+                low = np.where(low == 0, np.uint64(0x01020304), np.uint64(0xF1E2D3C4))
+            v = top | pre | low
+            keys, perm, hybrid = _sort_pairs_on_device(engine, v, 0)
+            order = np.argsort(v, kind="stable").astype(np.uint64)
+            assert hybrid and keys.tobytes() == v[order].tobytes() and np.array_equal(perm, order), (prefixes, lows)
+        # 366 groups of about 12288 pairs: some fit the window, some do not -> the plain loop; 400 groups: all fit
+        for groups, expect in ((366, False), (420, True)):
+            tops = rng.integers(0, groups, n, dtype=np.uint64)
+            v = ((tops // np.uint64(16)) << np.uint64(56)) | ((tops % np.uint64(16)) << np.uint64(48)) | rng.integers(0, 1 << 48, n, dtype=np.uint64)
+            keys, perm, hybrid = _sort_pairs_on_device(engine, v, 0)
+            order = np.argsort(v, kind="stable").astype(np.uint64)
+            assert keys.tobytes() == v[order].tobytes() and np.array_equal(perm, order), groups
+            assert hybrid == expect, groups
+        engine.lib.rs_debug_set_group_limit(engine.h, 2)
+        v = rng.integers(0, 1 << 64, n, dtype=np.uint64)
+        keys, perm, hybrid = _sort_pairs_on_device(engine, v, 0)
+        order = np.argsort(v, kind="stable").astype(np.uint64)
+        assert not hybrid and keys.tobytes() == v[order].tobytes() and np.array_equal(perm, order)
+    finally:
+        engine.lib.rs_debug_set_group_limit(engine.h, 0)
+        engine.set_hybrid(-1)
+        engine.set_precheck(True)
+
+
 def test_hybrid_over_chain_mode_sweeps(oracle):
     """The hybrid form over the chain-mode sweeps (per-XCD chains; the group table then adds the counts of the chains
     before a boundary): chain mode forced at test size in a child process (the switch is read once per process)."""

@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
   for (int it = 0; it < 5; ++it) {
     CK(hipMemcpy(d, src, n * 8, hipMemcpyDeviceToDevice));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, 1024, 17>), dim3(G), dim3(1024), 0, 0, a);
+    hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, 1024, 17>), dim3(G), dim3(1024), 0, 0, a);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = std::min(best, ms);
   }
