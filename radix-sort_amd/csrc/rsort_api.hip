@@ -86,7 +86,8 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
 constexpr size_t kHybridMinKeys = 120000000;   // hybrid form of 4-byte key sorts from here on (measured: 2^27 keys 1.19 against 1.34 ms, 2^26 keys 0.77 against 0.67 -- below, the fixed cost of 65536 workgroups outweighs the two sweeps saved)
-constexpr size_t kHybridMinKeysWide = 250000000;   // the same for 8-byte keys (2^28 keys: 7.2 against 7.6 ms; 2^27: 4.6 against 4.0 -- its 65536 workgroups run up to six LDS passes each)
+constexpr size_t kHybridMinKeysWide = 100000000;   // the same for 8-byte keys (two LDS passes + fix-up per group; 2^27 keys: 3.21 against 3.90 ms, 2^28: 5.0 against 7.6; 2^26: 2.36 against 2.06)
+constexpr size_t kHybridMinPairsWide = 64000000;    // and with a 4-byte payload (2^26 pairs: 2.71 against 2.88 ms, 2^27: 3.9 against 5.7, 2^28: 6.5 against 11.5)
 constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) neither pass skipping nor the order pre-check is worth a host synchronisation
 
 // Hybrid sort of 4-byte keys (rsort_groups.hpp): two sweeps on the top digits, then every group of equal top 16 bits is
@@ -766,7 +767,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       for (int p = 0; p < key_bytes; ++p)
         for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
       const double bound = static_cast<double>(mx[top_hi]) * static_cast<double>(mx[top_lo]) / static_cast<double>(n);   // largest group if the top digits are independent
-      hybrid = n >= (key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide) && bound <= 0.95 * group_cap;
+      hybrid = n >= (key_bytes == 4 ? kHybridMinKeys : pair_form ? kHybridMinPairsWide : kHybridMinKeysWide) && bound <= 0.95 * group_cap;
       for (int p = 0; p < top_lo; ++p) hybrid = hybrid && mx[p] <= n / 16;
     }
   }
