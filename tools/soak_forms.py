@@ -1,6 +1,7 @@
-"""Soak of the round-3 forms of large keys-only sorts -- hybrid (two sweeps + in-LDS group sort, forced on at these sizes),
-few distinct keys, the groups' prefix passes + fix-up and its fall-back, oversize groups -- on one context, random size,
-width, transform and key distribution, every result compared element by element with torch.sort of the same keys.
+"""Soak of the round-3 forms of large sorts -- hybrid (two sweeps + in-LDS group sort, forced on at these sizes), few
+distinct keys, the groups' prefix passes + fix-up and its fall-back, oversize groups, stable pairs of 8-byte keys and a 4-byte
+payload -- on one context, random size, width, transform and key distribution, every result compared element by element with
+torch's (stable) sort of the same keys.
 python tools/soak_forms.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -56,20 +57,28 @@ while time.time() < t_end:
     eng.lib.rs_debug_set_group_limit(eng.h, limit)
     sign = -(1 << (bits - 1))
     src = keys.clone()
+    pairs = kb == 8 and int(rng.integers(3)) == 0
+    vals = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
     torch.cuda.synchronize()
-    eng.sort_keys_(keys, xf)
+    if pairs:
+        eng.sort_pairs_(keys, vals, xf)
+    else:
+        eng.sort_keys_(keys, xf)
     eng.synchronize()
     forms["hybrid" if eng.lib.rs_debug_last_hybrid(eng.h) else "distinct" if eng.lib.rs_debug_last_distinct(eng.h) else "lsd"] += 1
     order = (lambda k: k if xf == 1 else (k ^ sign if xf == 0 else torch.where(k < 0, ~k ^ sign, k)))
-    want = torch.sort(order(src)).values
+    want, idx = torch.sort(order(src), stable=True)
     ok = bool((order(keys) == want).all().item())
+    if pairs:
+        ok = ok and bool((vals.to(torch.int64) == idx).all().item())
+        forms["pairs"] = forms.get("pairs", 0) + 1
     done += 1
     if not ok:
         fails += 1
-        print("FAIL", dict(kb=kb, xf=xf, n=n, kind=kind, hybrid=hybrid, limit=limit), flush=True)
+        print("FAIL", dict(kb=kb, xf=xf, n=n, kind=kind, hybrid=hybrid, limit=limit, pairs=pairs), flush=True)
     if done % 20 == 0:
         print(f"{done} sorts, {fails} failures, forms {forms}", flush=True)
-    del keys, src, want
+    del keys, src, want, idx, vals
 eng.lib.rs_debug_set_group_limit(eng.h, 0)
 print(f"soak_forms: {done} sorts in {budget:.0f} s, failures: {fails}, forms {forms}")
 sys.exit(1 if fails else 0)
