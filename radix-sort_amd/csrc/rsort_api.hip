@@ -87,6 +87,10 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 constexpr size_t kPerXcdMinTiles = 1024;
 constexpr size_t kHybridMinKeys = 120000000;   // hybrid form of 4-byte key sorts from here on (measured: 2^27 keys 1.19 against 1.34 ms, 2^26 keys 0.77 against 0.67 -- below, the fixed cost of 65536 workgroups outweighs the two sweeps saved)
 constexpr size_t kHybridMinKeysWide = 100000000;   // the same for 8-byte keys (two LDS passes + fix-up per group; 2^27 keys: 3.21 against 3.90 ms, 2^28: 5.0 against 7.6; 2^26: 2.36 against 2.06)
+// Narrow hybrid form (sort_device): 8-byte keys from the end of the mid-size regime up to kHybridMinKeysWide -- 5 / 16.7 / 67 M keys
+// 219 / 404 / 1358 us against 342 / 596 / 2075 us with eight passes.  4-byte keys: never by itself (whole keys in LDS, three
+// LDS passes: 16.7 M keys 308 against 241 us with four passes); rs_ctx_set_hybrid(2) forces it for tests.
+constexpr size_t kNarrowMinKeys = kHybridMinKeys, kNarrowMinKeysWide = 0;
 constexpr size_t kHybridMinPairsWide = 64000000;    // and with a 4-byte payload (2^26 pairs: 2.71 against 2.88 ms, 2^27: 3.9 against 5.7, 2^28: 6.5 against 11.5)
 constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) neither pass skipping nor the order pre-check is worth a host synchronisation
 
@@ -134,9 +138,9 @@ struct rs_ctx {
   bool profiling = false;
   bool precheck = true;    // order pre-check before sorting (rs_ctx_set_precheck)
   bool last_unchanged = false;   // the last sort_device found its input already in order and moved nothing
-  int hybrid_mode = -1;          // hybrid form of 4-byte key sorts: -1 chosen per sort, 0 never, 1 whenever the shape allows (rs_ctx_set_hybrid; RSORT_HYBRID at creation)
+  int hybrid_mode = -1;          // hybrid forms of keys-only sorts: -1 chosen per sort, 0 never, 1 the 16-bit-group form whenever the shape allows, 2 the narrow form whenever it does (rs_ctx_set_hybrid; RSORT_HYBRID at creation)
   unsigned group_max_vec = 0;    // test hook: groups of more vectors than this go to the big-group kernel (0 = what the LDS window holds)
-  bool last_hybrid = false;      // the last sort_device took the hybrid form
+  int last_hybrid = 0;          // the last sort_device took a hybrid form (1: groups of equal top 16 bits, 2: the narrow form)
   int last_string_levels = 0;    // MSD levels the last string sort took
   bool last_distinct = false;    // the last sort_device sorted by counting the few distinct keys (rsd::, rsort_groups.hpp)
   bool distinct_path = true;     // RSORT_DISTINCT=0 at creation switches that path off (tests, A/B timing)
@@ -481,7 +485,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   c->last_distinct = false;
   if (n < 2) { c->ev_count = 0; return RS_OK; }
   hipStream_t s = c->stream;
-  const int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
+  int passes = (end_bit - begin_bit + rsk::kRadixBits - 1) / rsk::kRadixBits;
   // RSORT_FORCE_WIDE=1 (tests, A/B timing): 8-byte descriptors and offsets regardless of n
   static const bool force_wide = [] { const char* e = std::getenv("RSORT_FORCE_WIDE"); return e && e[0] == '1'; }();
   const bool wide = n > kSmallDescLimit || (force_wide && !ws);   // (the static workspace holds 4-byte descriptor rows only, and its n <= 2^25 never needs more)
@@ -537,6 +541,21 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // descriptor buffer, and -- below -- no host synchronisation at all.
   const bool mid = tiles <= kAlwaysSweepTiles && !wide;
   int rc;
+  // Narrow hybrid form (keys-only sorts between the mid-size regime and the sizes where 65536 groups pay): the same two
+  // sweeps and in-LDS finish, but on the top 8 + b bits only, b chosen so that the 2^(8+b) groups hold about 0.7 windows
+  // each -- the sort is then a sort on the bit range [sort_begin, end_bit) (two digits: 8 bits and, on top, b bits) followed
+  // by the wide group kernel on the bits below.  Decided from n alone, before the histogram (which then covers only the two
+  // swept digits); whether the groups really fit is known from those counts, and the plain loop takes over when they do not.
+  int sort_begin = begin_bit, narrow_bits = 0;
+  if ((c->hybrid_mode == -1 || c->hybrid_mode == 2) && !ws && !mid && !wide && !forward_done && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) &&
+      begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic && (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0 &&
+      n < (key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide) && (c->hybrid_mode == 2 || n >= (key_bytes == 4 ? kNarrowMinKeys : kNarrowMinKeysWide))) {
+    int g = 9;
+    while (g < 16 && static_cast<double>(n) / static_cast<double>(size_t(1) << g) > 0.7 * kWideGroupCap) ++g;
+    narrow_bits = g - 8;
+    sort_begin = end_bit - g;
+    passes = 2;
+  }
   if (!ws) {
     if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
     if (!mid && (rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
@@ -675,7 +694,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   auto* next_cnt = reinterpret_cast<unsigned long long*>(ctrl + kCtrlNextCnt);
   rsk::HistArgs h{};
   h.keys = keys; h.ghist = ghist; h.n = n; h.fmask = fmask_rd; h.smask = smask_rd;
-  h.begin_bit = begin_bit; h.end_bit = end_bit; h.passes = passes;
+  h.begin_bit = sort_begin; h.end_bit = end_bit; h.passes = passes;
   h.chain_hist = chain ? chain_hist : nullptr;
   h.chain_keys = chain ? static_cast<uint64_t>(chain_tiles) * tile_keys(key_bytes, value_bytes, true) : 0;
   if (self_clearing) {
@@ -751,13 +770,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // rs_ctx_set_hybrid / RSORT_HYBRID: 0 never, 1 whenever the shape allows it (tests: any size, any distribution).
   const int hybrid_env = c->hybrid_mode;
   bool hybrid = false;
-  const int top_lo = key_bytes - 2, top_hi = key_bytes - 1;          // the two swept digits
+  const int top_lo = passes - 2, top_hi = passes - 1;                // the two swept digits (whole-key sorts: passes = key bytes; the narrow form: 0 and 1)
   // Pair form (8-byte keys, 4-byte payload; stable): the same two sweeps, the wide group kernel with the payload beside the
   // keys and a smaller window; a group beyond it sends the array -- as the sweeps left it: a stable rearrangement of the
   // input, keys transformed -- through the plain loop instead (there is no big-group kernel for pairs).
   const bool pair_form = value_bytes == 4 && key_bytes == 8 && vals != nullptr;
   const size_t group_cap = pair_form ? kWidePairGroupCap : key_bytes == 4 ? kGroupCap : kWideGroupCap;
-  if (hybrid_env != 0 && !ws && !mid && !wide && !forward_done && (value_bytes == 0 || pair_form) && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
+  if (hybrid_env != 0 && hybrid_env != 2 && !narrow_bits && !ws && !mid && !wide && !forward_done && (value_bytes == 0 || pair_form) && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
       end_bit == key_bytes * 8 && n_live == key_bytes && n < (size_t(1) << 32) && c->rank_by_lds_atomic &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
     if (hybrid_env == 1) {
@@ -771,8 +790,23 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       for (int p = 0; p < top_lo; ++p) hybrid = hybrid && mx[p] <= n / 16;
     }
   }
+  if (narrow_bits) {
+    unsigned long long mx[2] = {0, 0};
+    for (int p = 0; p < 2; ++p)
+      for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
+    const double bound = static_cast<double>(mx[1]) * static_cast<double>(mx[0]) / static_cast<double>(n);
+    hybrid = n_live == 2 && bound <= 0.95 * kWideGroupCap;
+    if (!hybrid) {     // a constant or skewed prefix: the plain loop, from the start (nothing has been moved; the checks that ran need not run again)
+      const int keep = c->hybrid_mode;
+      const bool keep_pre = c->precheck, keep_distinct = c->distinct_path;
+      c->hybrid_mode = 0; c->precheck = false; c->distinct_path = false;
+      rc = sort_device(c, keys, vals, alt_keys, alt_vals, n, key_bytes, value_bytes, transform, begin_bit, end_bit, ws, false);
+      c->hybrid_mode = keep; c->precheck = keep_pre; c->distinct_path = keep_distinct;
+      return rc;
+    }
+  }
   if (hybrid) {
-    c->last_hybrid = true;
+    c->last_hybrid = narrow_bits ? 2 : 1;
     if ((rc = ensure(c, c->groups, kGroupsBytes)) != RS_OK) return rc;
     live[0] = top_lo; live[1] = top_hi; n_live = 2;
   }
@@ -802,7 +836,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     a.fmask_in = done == 0 ? fmask_rd : 0; a.smask_in = done == 0 ? smask_rd : 0;              // first launched pass
     const bool stores_result = done == n_live - 1 && !hybrid;                                  // last launched pass (the hybrid form's group kernel stores the result)
     a.fmask_out = stores_result ? fmask : 0; a.smask_out = stores_result ? smask : 0;
-    a.shift = begin_bit + p * rsk::kRadixBits;
+    a.shift = sort_begin + p * rsk::kRadixBits;
     a.bits = std::min(rsk::kRadixBits, end_bit - a.shift);
     a.per_xcd_order = c->per_xcd_order && sweep_tiles >= kPerXcdMinTiles ? 1 : 0;
     a.incl_code = 2u + (done & 1);          // alternates over the LAUNCHED passes (descriptor parity, rsort_kernels.hpp)
@@ -815,7 +849,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       a.desc_local = c->desc_local ? 1 : 0;
       if (done + 1 < n_live) {
         a.next_cnt = next_cnt + static_cast<size_t>(done) * rsk::kXcds * rsk::kRadix;
-        a.next_shift = begin_bit + live[done + 1] * rsk::kRadixBits;
+        a.next_shift = sort_begin + live[done + 1] * rsk::kRadixBits;
         a.next_bits = std::min(rsk::kRadixBits, end_bit - a.next_shift);
       }
     }
@@ -856,10 +890,10 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     t.chain_tiles = sweep_chain ? chain_tiles : 0u;
     t.tile = static_cast<unsigned>(tile_keys(key_bytes, value_bytes, sweep_chain));
     t.n = static_cast<unsigned>(n);
-    t.shift_hi = top_hi * rsk::kRadixBits;
+    t.shift_hi = sort_begin + top_hi * rsk::kRadixBits;
     t.start = start;
     rsk::GroupArgs ga{};
-    ga.keys = keys; ga.start = start; ga.groups = kGroupCount; ga.low_bits = top_lo * rsk::kRadixBits;
+    ga.keys = keys; ga.start = start; ga.groups = kGroupCount; ga.low_bits = sort_begin + top_lo * rsk::kRadixBits;
     ga.fmask_out = fmask; ga.smask_out = smask;
     ga.big_list = big_list; ga.big_cap = kGroupCount;
     ga.n = static_cast<unsigned>(n); ga.error_flag = error_flag;
@@ -867,7 +901,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     ba.keys = keys; ba.alt = alt_keys; ba.start = start; ba.big_list = big_list; ba.big_cap = kGroupCount; ba.low_bits = ga.low_bits;
     ba.fmask_out = fmask; ba.smask_out = smask;
     ba.n = static_cast<unsigned>(n); ba.error_flag = error_flag;
-    if (key_bytes == 4) {
+    if (key_bytes == 4 && narrow_bits) {    // whole keys in LDS (the low part is wider than the 16-bit staging of the kernel below)
+      hipLaunchKernelGGL(rsk::group_table_kernel<uint32_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
+      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWideGroupCap) : static_cast<unsigned>(kWideGroupCap);   // (keys, for this kernel)
+      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(256u << narrow_bits), dim3(kWideGroupBlock), 0, s, ga);
+      if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
+      hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
+    } else if (key_bytes == 4) {
       hipLaunchKernelGGL(rsk::group_table_kernel<uint32_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
       ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, kGroupBlock * kGroupMaxVec) : kGroupBlock * kGroupMaxVec;
       hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
@@ -897,7 +937,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     } else {
       hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
       ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWideGroupCap) : static_cast<unsigned>(kWideGroupCap);   // (keys, for this kernel)
-      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
+      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(narrow_bits ? 256u << narrow_bits : kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint64_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     }
@@ -1177,7 +1217,7 @@ int rs_ctx_create(rs_ctx** out, int device) {
   }
   c->stream = c->own_stream;
   if (const char* e = std::getenv("RSORT_DISTINCT")) c->distinct_path = !(e[0] == '0');
-  if (const char* e = std::getenv("RSORT_HYBRID")) c->hybrid_mode = std::atoi(e) < 0 ? -1 : std::atoi(e) > 0 ? 1 : 0;
+  if (const char* e = std::getenv("RSORT_HYBRID")) c->hybrid_mode = std::atoi(e) < 0 ? -1 : std::atoi(e) > 2 ? 1 : std::atoi(e);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
@@ -1324,7 +1364,7 @@ int rs_ctx_set_precheck(rs_ctx* c, int enabled) {
 
 int rs_ctx_set_hybrid(rs_ctx* c, int mode) {
   if (!c) return RS_ERR_ARG;
-  if (mode < -1 || mode > 1) return fail(c, RS_ERR_ARG, "hybrid mode must be -1 (per sort), 0 (never) or 1 (whenever the shape allows)");
+  if (mode < -1 || mode > 2) return fail(c, RS_ERR_ARG, "hybrid mode must be -1 (per sort), 0 (never), 1 (16-bit groups whenever the shape allows) or 2 (narrow form whenever it does)");
   c->hybrid_mode = mode;
   return RS_OK;
 }
@@ -1336,7 +1376,7 @@ int rs_debug_set_group_limit(rs_ctx* c, unsigned max_vec) {
   c->group_max_vec = max_vec;
   return RS_OK;
 }
-int rs_debug_last_hybrid(const rs_ctx* c) { return c && c->last_hybrid ? 1 : 0; }
+int rs_debug_last_hybrid(const rs_ctx* c) { return c ? c->last_hybrid : 0; }   // 1: groups of equal top 16 bits, 2: the narrow form
 int rs_debug_last_distinct(const rs_ctx* c) { return c && c->last_distinct ? 1 : 0; }
 int rs_debug_set_distinct(rs_ctx* c, int on) { if (!c) return RS_ERR_ARG; c->distinct_path = on != 0; return RS_OK; }   // test hook: the few-distinct-keys path on / off
 int rs_debug_desc_local(const rs_ctx* c) { return c && c->desc_local ? 1 : 0; }      // what the chain probe of rs_ctx_create found

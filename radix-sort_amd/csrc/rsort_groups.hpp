@@ -338,19 +338,18 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
 // stable LDS passes of 8 bits, digits that are the same for the whole group skipped), one read and one write of the keys
 // whatever the number of passes.  8-byte keys at N = 2^30: 8 + 2 * 16 + 16 = 56 bytes per key instead of the canonical 136.
 // tile_sort_body for a group of len keys, instantiated for the smallest of 1, 2, 4, 8, 12, 16, ITEMS keys per thread that holds it
-// LOW = the low bits the group is sorted on (a constant of the calling kernel: the fix-up's compares fold to one word).
+// TOP: where the groups' prefix passes start (tile_sort_body): a constant of the calling kernel, so that the fix-up's compares
+// fold to one word; 0 = passes over all the low bits.  low_bits: the bits the group is sorted on (run time: the narrow form
+// leaves 48 to 55 of them, or 16 to 23 of a 4-byte key).
 #ifndef RS_FIX_PREFIX_BITS
-#define RS_FIX_PREFIX_BITS 16     // the passes cover the top 16 of the low bits, the fix-up the rest (0: passes over all the low bits)
+#define RS_FIX_PREFIX_BITS 16     // the passes cover at least the top 16 of the low bits, the fix-up the rest (0: passes over all the low bits)
 #endif
-template <typename K, typename V, int BLOCK, int ITEMS, int LOW, typename Smem>
-__device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, V* gv, unsigned len, K fmo, K smo) {
+template <typename K, typename V, int BLOCK, int ITEMS, int TOP, typename Smem>
+__device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, V* gv, unsigned len, K fmo, K smo, int low_bits) {
   const unsigned per = (len + BLOCK - 1) / BLOCK;        // (workgroup-uniform)
-  // (measured, 16384 keys per group: the fix-up costs what one and a half passes cost, so it pays from five passes on -- 8-byte
-  // keys: 48 low bits 41.9 -> 29.2 us per group; the 24 low bits of 4-byte keys are three passes and stay three passes)
-  constexpr int TOP = RS_FIX_PREFIX_BITS > 0 && LOW >= RS_FIX_PREFIX_BITS + 24 ? LOW - RS_FIX_PREFIX_BITS : 0;
   auto run = [&](auto it_tag) {
     constexpr int IT = decltype(it_tag)::value < ITEMS ? decltype(it_tag)::value : ITEMS;
-    tile_sort_body<K, V, BLOCK, IT, TOP>(s, gin, gout, gv, len, static_cast<K>(0), static_cast<K>(0), fmo, smo, 0, LOW);
+    tile_sort_body<K, V, BLOCK, IT, TOP>(s, gin, gout, gv, len, static_cast<K>(0), static_cast<K>(0), fmo, smo, 0, low_bits);
   };
   if (per <= 1) run(std::integral_constant<int, 1>{});
   else if (per <= 2) run(std::integral_constant<int, 2>{});
@@ -359,6 +358,11 @@ __device__ __forceinline__ void group_tile_sort(Smem& s, const K* gin, K* gout, 
   else if (per <= 12) run(std::integral_constant<int, 12>{});
   else if (per <= 16) run(std::integral_constant<int, 16>{});
   else run(std::integral_constant<int, ITEMS>{});
+}
+// (measured, 16384 keys per group: the fix-up costs what one and a half passes cost, so it pays from five passes on -- 8-byte
+// keys: 48 low bits 41.9 -> 29.2 us per group; the low bits of 4-byte keys are two or three passes and stay that)
+template <typename K> constexpr int group_fix_top(int low) {
+  return RS_FIX_PREFIX_BITS > 0 && sizeof(K) == 8 && low >= RS_FIX_PREFIX_BITS + 24 ? low - RS_FIX_PREFIX_BITS : 0;
 }
 
 // V = NoVal: keys only.  V = a 4-byte payload (a.vals): the stable pair form -- every pass and the fix-up keep equal keys in
@@ -384,8 +388,10 @@ __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
   }
   V* gv = nullptr;
   if constexpr (HAS_VAL) gv = static_cast<V*>(a.vals) + start;
-  group_tile_sort<K, V, BLOCK, ITEMS, (static_cast<int>(sizeof(K)) - 2) * 8>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, gv, len,
-                                                                             static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out));
+  // (8-byte keys: passes from bit 32 up -- 16 bits of prefix for the 48 low bits of the 16-bit-group form, up to 23 for the
+  // narrow form's 55 -- then the fix-up; 4-byte keys: passes over all the low bits)
+  group_tile_sort<K, V, BLOCK, ITEMS, group_fix_top<K>((static_cast<int>(sizeof(K)) - 2) * 8)>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, gv, len,
+                                                                                               static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), a.low_bits);
 }
 
 // The largest group of a start table (pair form: asked before anything is sorted).  *out must be zero.
@@ -428,8 +434,8 @@ __global__ __launch_bounds__(BLOCK) void group_sort_mid_kernel(MidArgs a) {
   const unsigned start = static_cast<unsigned>(part[0] + part[1] + part[2] + part[3]);
   const unsigned len = static_cast<unsigned>(a.counts[g]);
   if (len == 0) return;
-  group_tile_sort<K, NoVal, BLOCK, ITEMS, (static_cast<int>(sizeof(K)) - 1) * 8>(s, static_cast<const K*>(a.keys_in) + start, static_cast<K*>(a.keys_out) + start,
-                                                                                 static_cast<NoVal*>(nullptr), len, static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out));
+  group_tile_sort<K, NoVal, BLOCK, ITEMS, group_fix_top<K>((static_cast<int>(sizeof(K)) - 1) * 8)>(s, static_cast<const K*>(a.keys_in) + start, static_cast<K*>(a.keys_out) + start,
+                                                                                                   static_cast<NoVal*>(nullptr), len, static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), a.low_bits);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -73,7 +73,8 @@ class Engine:
         self._ck(self.lib.rs_ctx_set_tile_order(self.h, int(per_xcd)))
 
     def set_hybrid(self, mode: int):
-        """Hybrid form of 4-byte key sorts: -1 chosen per sort (default), 0 never, 1 whenever the key shape allows."""
+        """Hybrid forms of keys-only sorts: -1 chosen per sort (default), 0 never, 1 the 16-bit-group form whenever the key
+        shape allows, 2 the narrow form (sizes below 10^8) whenever it does."""
         self._ck(self.lib.rs_ctx_set_hybrid(self.h, int(mode)))
 
     def set_host_threads(self, threads: int):

@@ -111,6 +111,64 @@ def test_hybrid_prefix_runs_in_wide_groups(engine):
         engine.set_precheck(True)
 
 
+@pytest.mark.parametrize("name", ["u32", "i32", "f32", "u64", "i64", "f64"])
+def test_narrow_hybrid_matches_oracle(engine, oracle, name):
+    """The narrow hybrid form (sorts between the mid-size regime and 10^8 keys: two sweeps on the top 8 + b bits, b from the
+    size, then whole keys of every group sorted in LDS): every shape against the oracle, key-aligned buffers.  Shapes whose
+    groups cannot fit (256 values, float ramps) or whose swept bits are constant take the plain loop -- same result."""
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    engine.set_precheck(False)
+    engine.set_hybrid(2)
+    engine.lib.rs_debug_set_distinct(engine.h, 0)
+    try:
+        for n in (4_300_001, 9_999_999, (1 << 24) + 5):
+            for shape in shapes.SHAPES:
+                v = shapes.generate(name, n, shape)
+                got, _ = _sort_on_device(engine, v, xf, 1 if n & 1 else 0)
+                form = engine.lib.rs_debug_last_hybrid(engine.h)
+                assert got.tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
+                if shape == "randomized":
+                    assert form == 2, (name, n, form)
+                if shape == "duplicates":
+                    assert form == 0, (name, n, form)
+    finally:
+        engine.lib.rs_debug_set_distinct(engine.h, 1)
+        engine.set_hybrid(-1)
+        engine.set_precheck(True)
+
+
+def test_narrow_hybrid_prefixes(engine):
+    """Keys whose swept bits are constant (small integers), take few values (groups beyond the window: the plain loop, or the
+    big-group kernel when only some are), or whose low parts do (equal keys; 8-byte keys: long runs for the fix-up)."""
+    rng = np.random.Generator(np.random.PCG64(41))
+    engine.set_precheck(False)
+    engine.set_hybrid(2)
+    engine.lib.rs_debug_set_distinct(engine.h, 0)
+    try:
+        n = 6_000_003
+        for dtype, bits in ((np.uint32, 32), (np.uint64, 64)):
+            full = rng.integers(0, 1 << 63, n, dtype=np.uint64).astype(dtype) if bits == 32 else rng.integers(0, 1 << 64, n, dtype=np.uint64)
+            cases = {
+                "small integers": (full >> dtype(bits - 20)),
+                "top bits of 3 values": (full >> dtype(2)) | (rng.integers(0, 3, n, dtype=np.uint64).astype(dtype) << dtype(bits - 2)),
+                "one heavy prefix": np.where(rng.random(n) < 0.02, full >> dtype(12), full),
+                "low part of 5 values": (full & ~dtype((1 << (bits - 16)) - 1)) | rng.integers(0, 5, n, dtype=np.uint64).astype(dtype),
+                "mid prefix of 4 values": (full & ~dtype(0xFFFF << (bits - 32))) | (rng.integers(0, 4, n, dtype=np.uint64).astype(dtype) << dtype(bits - 30)),
+            }
+            for what, v in cases.items():
+                got, _ = _sort_on_device(engine, v, 0)
+                assert got.tobytes() == np.sort(v).tobytes(), (what, dtype)
+            engine.lib.rs_debug_set_group_limit(engine.h, 100)           # groups of more than 400 keys: the big-group kernel
+            got, _ = _sort_on_device(engine, full, 0)
+            assert got.tobytes() == np.sort(full).tobytes() and engine.lib.rs_debug_last_hybrid(engine.h) == 2, dtype
+            engine.lib.rs_debug_set_group_limit(engine.h, 0)
+    finally:
+        engine.lib.rs_debug_set_group_limit(engine.h, 0)
+        engine.lib.rs_debug_set_distinct(engine.h, 1)
+        engine.set_hybrid(-1)
+        engine.set_precheck(True)
+
+
 def _sort_pairs_on_device(engine, v, xf, offset=0):
     """(v, 0..n-1) through rs_sort_pairs_device, 4-byte payload: (sorted keys, payload = the stable permutation, took the hybrid form)."""
     import torch
