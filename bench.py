@@ -182,10 +182,40 @@ def bench_single(args):
         torch.cuda.empty_cache()
     pair_rows = [bench_pairs(eng, torch, dev, spec, args) for spec in args.pairs]
     eng.set_profiling(False)
+    size_rows = [bench_size(eng, torch, dev, name, m) for m in args.sizes for name in ("u32", "u64")]
     string_rows = [bench_strings(eng, m) for m in args.strings]
     string_rows += [bench_strings(eng, args.strings[0], shape) for shape in args.string_shapes if args.strings]
     eng.close()
-    return headline, rows, dominant, pair_rows, string_rows
+    return headline, rows, dominant, pair_rows, string_rows, size_rows
+
+
+def bench_size(eng, torch, dev, name, n):
+    """Device-resident keys-only sort at the sizes of the reference's own benchmark (main.cpp:19-21: up to 10^8; BASELINE
+    configs[0] is the 10^8 uint32 row on the host CPU): randomized keys, order pre-check on, host clock around call + wait,
+    median of 20.  Below the headline size other forms run (narrow hybrid for 8-byte keys, four-pass loop for 4-byte keys)."""
+    from radix_sort_amd import shapes
+    dt, kb, xf = shapes.KEY_TYPES[name]
+    src = shapes.generate_device(name, n, "randomized", dev)
+    work = torch.empty_like(src)
+    alt = torch.empty_like(src)
+    eng.set_precheck(True)
+    ts = []
+    for it in range(23):
+        work.copy_(src)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.sort_keys_(work, xf, alt=alt)
+        eng.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[3:])
+    sec = ts[len(ts) // 2]
+    form = {0: "lsd", 1: "hybrid (groups of equal top 16 bits)", 2: "narrow hybrid (groups of equal top 9-15 bits)"}[int(eng.lib.rs_debug_last_hybrid(eng.h))]
+    sign = -(1 << 31) if kb == 4 else -(1 << 63)
+    okey = work ^ sign
+    ok = bool((okey[1:] >= okey[:-1]).all().item()) and bool((work.sum() == src.sum()).item())
+    b_key = algorithmic_bytes_per_key(kb)
+    return {"type": name, "shape": "randomized", "n": n, "ms": sec * 1e3, "gkeys_s": n / sec / 1e9, "form": form,
+            "hbm_frac": n * b_key / sec / 1e9 / HBM_PEAK_GBS, "sorted_and_checksum": ok}
 
 
 def bench_pairs(eng, torch, dev, spec, args):
@@ -392,6 +422,7 @@ def main():
     ap.add_argument("--pairs-n", type=int, default=1 << 29)
     ap.add_argument("--strings", default="10000000,50000000", help="string counts for the rs_sort_strings rows")
     ap.add_argument("--string-shapes", default="prefix24,shortlex,dup256", help="harder string inputs, at the first --strings count")
+    ap.add_argument("--sizes", default="10000000,100000000", help="device-resident randomized rows at the reference benchmark's own sizes")
     ap.add_argument("--composite-n", type=int, default=10_000_000, help="0 = skip the configs[3] row")
     ap.add_argument("--cpu-n", type=int, default=100_000_000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -402,6 +433,7 @@ def main():
     args.extra_shapes = [s for s in args.extra_shapes.split(",") if s]
     args.pairs = [p for p in args.pairs.split(",") if p]
     args.strings = [int(x) for x in args.strings.split(",") if x]
+    args.sizes = [int(x) for x in args.sizes.split(",") if x]
     args.string_shapes = [x for x in args.string_shapes.split(",") if x]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -409,7 +441,7 @@ def main():
         from radix_sort_amd import dist_bench
         return dist_bench.main(args)
 
-    headline, rows, roof, pair_rows, string_rows = bench_single(args)
+    headline, rows, roof, pair_rows, string_rows, size_rows = bench_single(args)
     out = {
         "metric": "Gkeys/s (uint32/uint64, N=2^30) at 1/2/4/8 MI355X; % HBM roofline",
         "value": headline["gkeys_s"], "unit": "Gkeys/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -422,6 +454,7 @@ def main():
         "rows": rows,
         "pair_rows": pair_rows,
         "string_rows": string_rows,
+        "size_rows": size_rows,
     }
     if args.composite_n:
         out["composite_row"] = bench_composite(args.composite_n)

@@ -4,9 +4,9 @@
 tag="$1"; R=$GRAFT_REPO_ROOT
 cd $R && timeout -k 10 600 python bench.py --steps 5 --warmup 2 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof -- python3 $R/bench.py --steps 5 --warmup 2 --shapes randomized --extra-types "" --pairs "" --strings "" --composite-n 0 --no-cpu > $R/gpurun_out/${tag}_bench_rocprof.json 2> $R/gpurun_out/${tag}_bench_rocprof.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof -- python3 $R/bench.py --steps 5 --warmup 2 --shapes randomized --extra-types "" --pairs "" --strings "" --sizes "" --composite-n 0 --no-cpu > $R/gpurun_out/${tag}_bench_rocprof.json 2> $R/gpurun_out/${tag}_bench_rocprof.err || exit 1
 cd $R && python tools/rocpd_kernel_stats.py gpurun_out/${tag}_prof "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --shapes randomized (u32, u64; N = 2^30)" > gpurun_out/${tag}_kernel_stats_randomized.csv || exit 1
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_dup -- python3 $R/bench.py --steps 5 --warmup 2 --shapes duplicates --extra-types "" --pairs "" --strings "" --composite-n 0 --no-cpu > $R/gpurun_out/${tag}_bench_duplicates_rocprof.json 2> $R/gpurun_out/${tag}_bench_duplicates_rocprof.err || exit 1
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_dup -- python3 $R/bench.py --steps 5 --warmup 2 --shapes duplicates --extra-types "" --pairs "" --strings "" --sizes "" --composite-n 0 --no-cpu > $R/gpurun_out/${tag}_bench_duplicates_rocprof.json 2> $R/gpurun_out/${tag}_bench_duplicates_rocprof.err || exit 1
 cd $R && python tools/rocpd_kernel_stats.py gpurun_out/${tag}_prof_dup "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --shapes duplicates (u32, u64; N = 2^30)" > gpurun_out/${tag}_kernel_stats_duplicates.csv || exit 1
 for kb in 4 8; do
   tools/pmc_pass.sh ${tag}_f$kb "FETCH_SIZE" $kb || exit 1
