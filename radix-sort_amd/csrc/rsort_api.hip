@@ -394,12 +394,12 @@ void launch_reverse_k(void* keys, size_t n, hipStream_t s) {
 }
 
 // Sort by counting the distinct keys (see the call in sort_device).  *done = 1 when the array has been sorted that way.
-int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t fmask, uint64_t smask, int* done) {
+int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t fmask, uint64_t smask, int* done, unsigned long long* span) {
   *done = 0;
   hipStream_t s = c->stream;
   constexpr size_t G = rsd::kGlobalSlots, D = rsd::kDistinctMax;
   constexpr size_t kOffCnt = G * 8, kOffOnes = kOffCnt + G * 8, kOffUsed = kOffOnes + 8, kOffSorted = kOffUsed + 8,
-                   kOffStarts = kOffSorted + (D + 1) * 8, kBytes = kOffStarts + (D + 2) * 8;
+                   kOffStarts = kOffSorted + (D + 1) * 8, kOffSpan = kOffStarts + (D + 2) * 8, kBytes = kOffSpan + 16;
   int rc;
   if ((rc = ensure(c, c->distinct, kBytes)) != RS_OK) return rc;
   char* d = static_cast<char*>(c->distinct.p);
@@ -415,8 +415,16 @@ int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t f
   RS_HIP(c, hipMemsetAsync(a.used, 0, 8, s));
   a.n = std::min<size_t>(n, size_t(1) << 18); a.probe = 1;
   launch(1);
+  // (riding on the same wait: which key bits differ at all, over a sample spread across the array -- sort_device's narrow form asks)
+  auto* d_span = reinterpret_cast<unsigned long long*>(d + kOffSpan);
+  RS_HIP(c, hipMemsetAsync(d_span, 0xFF, 8, s));
+  RS_HIP(c, hipMemsetAsync(d_span + 1, 0, 8, s));
+  if (key_bytes == 4) hipLaunchKernelGGL(rsd::bit_span_kernel<uint32_t>, dim3(1), dim3(1024), 0, s, static_cast<const uint32_t*>(keys), static_cast<uint64_t>(n), d_span);
+  else hipLaunchKernelGGL(rsd::bit_span_kernel<uint64_t>, dim3(1), dim3(1024), 0, s, static_cast<const uint64_t*>(keys), static_cast<uint64_t>(n), d_span);
   RS_HIP(c, hipMemcpyAsync(used, a.used, 8, hipMemcpyDeviceToHost, s));
+  RS_HIP(c, hipMemcpyAsync(span, d_span, 16, hipMemcpyDeviceToHost, s));
   RS_HIP(c, hipStreamSynchronize(s));
+  span[2] = 1;                                              // known
   if (used[0] > D) return RS_OK;
   // 2. the whole array
   int ev = 0;
@@ -541,21 +549,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // descriptor buffer, and -- below -- no host synchronisation at all.
   const bool mid = tiles <= kAlwaysSweepTiles && !wide;
   int rc;
-  // Narrow hybrid form (keys-only sorts between the mid-size regime and the sizes where 65536 groups pay): the same two
-  // sweeps and in-LDS finish, but on the top 8 + b bits only, b chosen so that the 2^(8+b) groups hold about 0.7 windows
-  // each -- the sort is then a sort on the bit range [sort_begin, end_bit) (two digits: 8 bits and, on top, b bits) followed
-  // by the wide group kernel on the bits below.  Decided from n alone, before the histogram (which then covers only the two
-  // swept digits); whether the groups really fit is known from those counts, and the plain loop takes over when they do not.
-  int sort_begin = begin_bit, narrow_bits = 0;
-  if ((c->hybrid_mode == -1 || c->hybrid_mode == 2) && !ws && !mid && !wide && !forward_done && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) &&
-      begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic && (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0 &&
-      n < (key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide) && (c->hybrid_mode == 2 || n >= (key_bytes == 4 ? kNarrowMinKeys : kNarrowMinKeysWide))) {
-    int g = 9;
-    while (g < 16 && static_cast<double>(n) / static_cast<double>(size_t(1) << g) > 0.7 * kWideGroupCap) ++g;
-    narrow_bits = g - 8;
-    sort_begin = end_bit - g;
-    passes = 2;
-  }
+  unsigned long long span[3] = {0, 0, 0};     // AND and OR of a sample of the keys, [2] = known (sort_few_distinct)
   if (!ws) {
     if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
     if (!mid && (rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
@@ -639,8 +633,30 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   if (c->distinct_path && !ws && !mid && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 && end_bit == key_bytes * 8 &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
     int done = 0;
-    if ((rc = sort_few_distinct(c, keys, n, key_bytes, fmask, smask, &done)) != RS_OK) return rc;
+    if ((rc = sort_few_distinct(c, keys, n, key_bytes, fmask, smask, &done, span)) != RS_OK) return rc;
     if (done) return RS_OK;
+  }
+
+  // Narrow hybrid form (keys-only sorts between the mid-size regime and the sizes where 65536 groups pay): the same two
+  // sweeps and in-LDS finish, but on the top 8 + b bits only, b chosen so that the 2^(8+b) groups hold about 0.7 windows
+  // each -- the sort is then a sort on the bit range [sort_begin, end_bit) (two digits: 8 bits and, on top, b bits) followed
+  // by the wide group kernel on the bits below.  Decided from n alone, before the histogram (which then covers only the two
+  // swept digits); whether the groups really fit is known from those counts, and the plain loop takes over when they do not.
+  int sort_begin = begin_bit, narrow_bits = 0;
+  if ((c->hybrid_mode == -1 || c->hybrid_mode == 2) && !ws && !mid && !wide && !forward_done && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) &&
+      begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic && (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0 &&
+      n < (key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide) && (c->hybrid_mode == 2 || n >= (key_bytes == 4 ? kNarrowMinKeys : kNarrowMinKeysWide))) {
+    int g = 9;
+    while (g < 16 && static_cast<double>(n) / static_cast<double>(size_t(1) << g) > 0.7 * kWideGroupCap) ++g;
+    // (the sample of the few-distinct probe, when it ran: bits that are the same in every sampled key.  The top g bits must
+    // all differ somewhere, or the groups cannot be balanced -- 8-byte keys that hold small integers -- and the plain loop,
+    // which skips constant digits, is the better start.  A hint only: the histogram below still decides.)
+    const unsigned long long need = ((1ull << g) - 1ull) << (end_bit - g);
+    if (!span[2] || (((span[0] ^ span[1]) & need) == need) || c->hybrid_mode == 2) {
+      narrow_bits = g - 8;
+      sort_begin = end_bit - g;
+      passes = 2;
+    }
   }
 
   unsigned chain_tiles = 0, chunk_shift = 0, chunk_mul = 0;

@@ -769,6 +769,26 @@ __global__ __launch_bounds__(BLOCK) void distinct_collect_kernel(CollectArgs a) 
   }
 }
 
+// Which bits differ among the keys?  AND and OR over 4096 keys spread evenly over the array (one workgroup, microseconds):
+// a hint for the narrow hybrid form, which is pointless when the bits it would sweep are the same for every key (small
+// integers in 8-byte keys).  out[0] must be all ones, out[1] zero.
+template <typename K>
+__global__ __launch_bounds__(1024) void bit_span_kernel(const K* keys, uint64_t n, unsigned long long* out) {
+  const uint64_t stride = n / 4096u ? n / 4096u : 1u;
+  unsigned long long a = ~0ull, o = 0ull;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t i = (static_cast<uint64_t>(j) * 1024u + threadIdx.x) * stride;
+    if (i < n) { const unsigned long long k = static_cast<unsigned long long>(keys[i]); a &= k; o |= k; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a &= static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(a), off, 64));
+    o |= static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(o), off, 64));
+  }
+  if ((threadIdx.x & 63u) == 0) { atomicAnd(&out[0], a); atomicOr(&out[1], o); }
+}
+
 struct FillArgs {
   void* out;
   uint64_t n;

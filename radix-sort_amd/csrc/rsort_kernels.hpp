@@ -947,7 +947,10 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void onesw
     if constexpr (full) {      // (the ragged last tile ranks by plain adds: correct for any digits, and it is one tile)
       const unsigned d = digit_at(key[0], a.shift, a.bits);
       const unsigned heads = static_cast<unsigned>(__popcll(__ballot(digit_of_lane_below(d) != d)));   // runs in the wave's first round
-      runs_group = heads > 1 && heads <= 20;
+#ifndef RS_RANK_RUNS_MAX
+#define RS_RANK_RUNS_MAX 20
+#endif
+      runs_group = heads > 1 && heads <= RS_RANK_RUNS_MAX;
       special = runs_group;
 #pragma unroll
       for (int g = 0; g < ITEMS; g += 4) {

@@ -162,6 +162,15 @@ def test_narrow_hybrid_prefixes(engine):
             got, _ = _sort_on_device(engine, full, 0)
             assert got.tobytes() == np.sort(full).tobytes() and engine.lib.rs_debug_last_hybrid(engine.h) == 2, dtype
             engine.lib.rs_debug_set_group_limit(engine.h, 0)
+        # as shipped (form chosen by the library): 8-byte keys of this size take the narrow form when the bits it sweeps differ
+        # among the keys (a sample spread over the array says so: random keys, a ramp), not when they hold small integers
+        engine.set_hybrid(-1)
+        engine.lib.rs_debug_set_distinct(engine.h, 1)
+        full = rng.integers(0, 1 << 64, n, dtype=np.uint64)
+        for what, v, form in (("random", full, 2), ("ramp", np.sort(full), 2), ("small integers", full >> np.uint64(28), 0),
+                              ("4-byte keys", full.astype(np.uint32), 0)):
+            got, _ = _sort_on_device(engine, v, 0)
+            assert got.tobytes() == np.sort(v).tobytes() and engine.lib.rs_debug_last_hybrid(engine.h) == form, what
     finally:
         engine.lib.rs_debug_set_group_limit(engine.h, 0)
         engine.lib.rs_debug_set_distinct(engine.h, 1)
