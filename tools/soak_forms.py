@@ -15,7 +15,7 @@ eng = rs.Engine(0, stream=torch.cuda.current_stream().cuda_stream)
 eng.set_precheck(False)
 t_end = time.time() + budget
 done = fails = 0
-forms = {"hybrid": 0, "distinct": 0, "lsd": 0}
+forms = {"hybrid": 0, "narrow": 0, "distinct": 0, "lsd": 0}
 
 
 def rand_bits(n, kb):
@@ -52,7 +52,7 @@ while time.time() < t_end:
         m = n // 40
         a = torch.randint(0, n, (m,), device="cuda"); b = torch.randint(0, n, (m,), device="cuda")
         tmp = keys[a].clone(); keys[a] = keys[b]; keys[b] = tmp
-    hybrid = int(rng.choice([-1, 1, 1]))
+    hybrid = int(rng.choice([-1, -1, 1, 1, 2]))               # as shipped / 16-bit groups forced / narrow form forced
     eng.set_hybrid(hybrid)
     eng.lib.rs_debug_set_group_limit(eng.h, limit)
     sign = -(1 << (bits - 1))
@@ -65,7 +65,8 @@ while time.time() < t_end:
     else:
         eng.sort_keys_(keys, xf)
     eng.synchronize()
-    forms["hybrid" if eng.lib.rs_debug_last_hybrid(eng.h) else "distinct" if eng.lib.rs_debug_last_distinct(eng.h) else "lsd"] += 1
+    took = int(eng.lib.rs_debug_last_hybrid(eng.h))
+    forms["hybrid" if took == 1 else "narrow" if took == 2 else "distinct" if eng.lib.rs_debug_last_distinct(eng.h) else "lsd"] += 1
     order = (lambda k: k if xf == 1 else (k ^ sign if xf == 0 else torch.where(k < 0, ~k ^ sign, k)))
     want, idx = torch.sort(order(src), stable=True)
     ok = bool((order(keys) == want).all().item())
