@@ -85,7 +85,7 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // where it pays -- sorts of at least this many tiles (16 M four-byte keys), which saturate the GPU on their own -- and
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
-constexpr size_t kHybridMinKeys = 120000000;   // hybrid form of 4-byte key sorts from here on (measured: 2^27 keys 1.19 against 1.34 ms, 2^26 keys 0.77 against 0.67 -- below, the fixed cost of 65536 workgroups outweighs the two sweeps saved)
+constexpr size_t kHybridMinKeys = 64000000;    // hybrid form of 4-byte key sorts from here on (four-wave group kernel; 2^26 keys 655 against 674 us, 10^8 875 against 970; 2^25 429 against 385 -- below, the fixed cost of 65536 workgroups outweighs the two sweeps saved)
 constexpr size_t kHybridMinKeysWide = 100000000;   // the same for 8-byte keys (two LDS passes + fix-up per group; 2^27 keys: 3.21 against 3.90 ms, 2^28: 5.0 against 7.6; 2^26: 2.36 against 2.06)
 // Narrow hybrid form (sort_device): 8-byte keys from the end of the mid-size regime up to kHybridMinKeysWide -- 5 / 16.7 / 67 M keys
 // 219 / 404 / 1358 us against 342 / 596 / 2075 us with eight passes.  4-byte keys: never by itself (whole keys in LDS, three
@@ -106,6 +106,8 @@ constexpr size_t kWideGroupCap = size_t(kWideGroupBlock) * kWideGroupItems;
 // mid-size sorts of 4-byte keys: groups of equal top byte, whole keys in LDS (rsk::group_sort_mid_kernel), 1024 x 20 keys = 80 KB
 constexpr int kMidGroupBlock = 1024;
 constexpr int kMidGroupItems = 20;
+constexpr int kSmallGroupBlock = 256;          // 4-byte keys, groups of at most 256 x 10 x 4 - 3 = 10237 keys (the kernel wants one thread per digit: not fewer)
+constexpr size_t kSmallGroupMeanMax = 6500;    // mean group size below which the four-wave workgroups sort the groups (n below 4.26e8; measured 1.3e8 / 2.7e8 / 4e8 keys: 1030 / 1747 / 2525 against 1164 / 1913 / 2681 us)
 constexpr int kWidePairGroupItems = 12;   // 8-byte keys with a 4-byte payload: 1024 x 12 = 12288 pairs = 144 KB
 constexpr size_t kWidePairGroupCap = size_t(1024) * kWidePairGroupItems;
 constexpr unsigned kGroupCount = 65536;
@@ -484,6 +486,11 @@ int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t f
   return RS_OK;
 }
 
+size_t small_group_mean_max() {     // RSORT_SMALL_GROUP_MEAN (A/B timing): mean group size below which the four-wave workgroups sort the groups
+  static const size_t v = [] { const char* e = std::getenv("RSORT_SMALL_GROUP_MEAN"); return e ? static_cast<size_t>(std::atol(e)) : kSmallGroupMeanMax; }();
+  return v;
+}
+
 // The device sort proper.  keys/vals are sorted in place; alt_* are same-size scratch.
 int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_vals, size_t n, int key_bytes,
                 int value_bytes, int transform, int begin_bit, int end_bit, const Workspace* ws = nullptr, bool forward_done = false) {
@@ -791,7 +798,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // keys and a smaller window; a group beyond it sends the array -- as the sweeps left it: a stable rearrangement of the
   // input, keys transformed -- through the plain loop instead (there is no big-group kernel for pairs).
   const bool pair_form = value_bytes == 4 && key_bytes == 8 && vals != nullptr;
-  const size_t group_cap = pair_form ? kWidePairGroupCap : key_bytes == 4 ? kGroupCap : kWideGroupCap;
+  const size_t group_cap = pair_form ? kWidePairGroupCap : key_bytes == 4 ? (n / kGroupCount < small_group_mean_max() ? size_t(kSmallGroupBlock) * kGroupMaxVec * 4 - 3 : kGroupCap) : kWideGroupCap;
   if (hybrid_env != 0 && hybrid_env != 2 && !narrow_bits && !ws && !mid && !wide && !forward_done && (value_bytes == 0 || pair_form) && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
       end_bit == key_bytes * 8 && n_live == key_bytes && n < (size_t(1) << 32) && c->rank_by_lds_atomic &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
@@ -925,8 +932,16 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     } else if (key_bytes == 4) {
       hipLaunchKernelGGL(rsk::group_table_kernel<uint32_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
-      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, kGroupBlock * kGroupMaxVec) : kGroupBlock * kGroupMaxVec;
-      hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
+      // Small groups (sorts of some 10^7 to 10^8 keys: a thousand keys per group) go to workgroups of four waves, six of
+      // which share a CU, instead of leaving most of 512 threads idle; the few groups beyond their window (10237 keys) to the
+      // big-group kernel as ever.
+      const bool small_groups = n / kGroupCount < small_group_mean_max();
+      const unsigned window_vec = small_groups ? kSmallGroupBlock * kGroupMaxVec : kGroupBlock * kGroupMaxVec;
+      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, window_vec) : window_vec;
+      if (small_groups)
+        hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kSmallGroupBlock, kGroupMaxVec, 6>), dim3(kGroupCount), dim3(kSmallGroupBlock), 0, s, ga);
+      else
+        hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     } else if (pair_form) {
