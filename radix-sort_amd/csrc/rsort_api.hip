@@ -665,6 +665,23 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       passes = 2;
     }
   }
+  // Prefixed hybrid form: keys whose leading t bits (1..7) are the same in every key -- what a multi-GPU rank holds after the
+  // exchange when the split points fall on top-digit edges (dist.py snaps them there when that costs no balance), or plain
+  // data of a narrower range.  Groups of equal top 16 bits would be 2^t times the usual size; the 16 bits BELOW the prefix
+  // make groups of the usual size.  So the sort is a sort on the bit range [end - t - 16, end): two full digits, which are
+  // swept, and on top a partial digit of t bits that must come out constant -- the histogram says so exactly, the sample
+  // (span) only suggests it -- followed by the in-LDS finish of the end - t - 16 bits below.
+  int prefix_bits = 0;
+  if (!narrow_bits && (c->hybrid_mode == -1 || c->hybrid_mode == 3) && span[2] && !ws && !mid && !forward_done && value_bytes == 0 &&
+      (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic &&
+      (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0 && n < (size_t(1) << 32) &&
+      (c->hybrid_mode == 3 || n >= (key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide))) {
+    const unsigned long long vary = (span[0] ^ span[1]) & all;
+    if (vary) {
+      const int t = end_bit - (64 - __builtin_clzll(vary));       // leading bits the sampled keys share
+      if (t >= 1 && t <= 7) { prefix_bits = t; sort_begin = end_bit - t - 16; passes = 3; }
+    }
+  }
 
   unsigned chain_tiles = 0, chunk_shift = 0, chunk_mul = 0;
   if (chain) {
@@ -793,13 +810,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // rs_ctx_set_hybrid / RSORT_HYBRID: 0 never, 1 whenever the shape allows it (tests: any size, any distribution).
   const int hybrid_env = c->hybrid_mode;
   bool hybrid = false;
-  const int top_lo = passes - 2, top_hi = passes - 1;                // the two swept digits (whole-key sorts: passes = key bytes; the narrow form: 0 and 1)
+  const int top_lo = prefix_bits ? 0 : passes - 2, top_hi = prefix_bits ? 1 : passes - 1;   // the two swept digits (whole-key sorts: passes = key bytes; the narrow and the prefixed form: 0 and 1)
   // Pair form (8-byte keys, 4-byte payload; stable): the same two sweeps, the wide group kernel with the payload beside the
   // keys and a smaller window; a group beyond it sends the array -- as the sweeps left it: a stable rearrangement of the
   // input, keys transformed -- through the plain loop instead (there is no big-group kernel for pairs).
   const bool pair_form = value_bytes == 4 && key_bytes == 8 && vals != nullptr;
   const size_t group_cap = pair_form ? kWidePairGroupCap : key_bytes == 4 ? (n / kGroupCount < small_group_mean_max() ? size_t(kSmallGroupBlock) * kGroupMaxVec * 4 - 3 : kGroupCap) : kWideGroupCap;
-  if (hybrid_env != 0 && hybrid_env != 2 && !narrow_bits && !ws && !mid && !wide && !forward_done && (value_bytes == 0 || pair_form) && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
+  if (hybrid_env != 0 && hybrid_env != 2 && hybrid_env != 3 && !narrow_bits && !prefix_bits && !ws && !mid && !(sweep_chain ? wide_chain : wide) && !forward_done && (value_bytes == 0 || pair_form) && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
       end_bit == key_bytes * 8 && n_live == key_bytes && n < (size_t(1) << 32) && c->rank_by_lds_atomic &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
     if (hybrid_env == 1) {
@@ -809,16 +826,28 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       for (int p = 0; p < key_bytes; ++p)
         for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
       const double bound = static_cast<double>(mx[top_hi]) * static_cast<double>(mx[top_lo]) / static_cast<double>(n);   // largest group if the top digits are independent
-      hybrid = n >= (key_bytes == 4 ? kHybridMinKeys : pair_form ? kHybridMinPairsWide : kHybridMinKeysWide) && bound <= 0.95 * group_cap;
+      hybrid = n >= (key_bytes == 4 ? kHybridMinKeys : pair_form ? kHybridMinPairsWide : kHybridMinKeysWide) && bound <= (key_bytes == 8 && !pair_form ? 0.97 : 0.95) * group_cap;
       for (int p = 0; p < top_lo; ++p) hybrid = hybrid && mx[p] <= n / 16;
     }
   }
-  if (narrow_bits) {
+  uint64_t shared_prefix = 0;      // prefixed form: the bits above the swept digits, in place
+  if (narrow_bits || prefix_bits) {
     unsigned long long mx[2] = {0, 0};
     for (int p = 0; p < 2; ++p)
       for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
     const double bound = static_cast<double>(mx[1]) * static_cast<double>(mx[0]) / static_cast<double>(n);
-    hybrid = n_live == 2 && bound <= 0.95 * kWideGroupCap;
+    if (narrow_bits) {
+      hybrid = n_live == 2 && bound <= 0.95 * kWideGroupCap;
+    } else {
+      int only = -1;               // the one value of the partial digit on top, if it is one
+      for (int d = 0; d < 256; ++d)
+        if (h_hist_keep[2 * 256 + d] == n) only = d;
+      // (0.97 of the window for 8-byte keys: a rank of eight holds 2^30 keys give or take half a per cent, groups of 16384 +- 128 keys in a window of 17408)
+      hybrid = only >= 0 && n_live == 2 && live[0] == 0 && live[1] == 1 && !(sweep_chain ? wide_chain : wide) && bound <= (key_bytes == 8 ? 0.97 : 0.95) * group_cap;
+      if (c->hybrid_mode == -1)
+        for (int p = 0; p < 2; ++p) hybrid = hybrid && mx[p] <= n / 16;
+      if (hybrid) shared_prefix = static_cast<uint64_t>(only) << (end_bit - prefix_bits);
+    }
     if (!hybrid) {     // a constant or skewed prefix: the plain loop, from the start (nothing has been moved; the checks that ran need not run again)
       const int keep = c->hybrid_mode;
       const bool keep_pre = c->precheck, keep_distinct = c->distinct_path;
@@ -829,7 +858,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     }
   }
   if (hybrid) {
-    c->last_hybrid = narrow_bits ? 2 : 1;
+    c->last_hybrid = narrow_bits ? 2 : prefix_bits ? 3 : 1;
     if ((rc = ensure(c, c->groups, kGroupsBytes)) != RS_OK) return rc;
     live[0] = top_lo; live[1] = top_hi; n_live = 2;
   }
@@ -917,7 +946,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     t.start = start;
     rsk::GroupArgs ga{};
     ga.keys = keys; ga.start = start; ga.groups = kGroupCount; ga.low_bits = sort_begin + top_lo * rsk::kRadixBits;
-    ga.fmask_out = fmask; ga.smask_out = smask;
+    ga.fmask_out = fmask; ga.smask_out = smask; ga.top_or = shared_prefix;
     ga.big_list = big_list; ga.big_cap = kGroupCount;
     ga.n = static_cast<unsigned>(n); ga.error_flag = error_flag;
     rsk::BigArgs ba{};
@@ -1248,7 +1277,7 @@ int rs_ctx_create(rs_ctx** out, int device) {
   }
   c->stream = c->own_stream;
   if (const char* e = std::getenv("RSORT_DISTINCT")) c->distinct_path = !(e[0] == '0');
-  if (const char* e = std::getenv("RSORT_HYBRID")) c->hybrid_mode = std::atoi(e) < 0 ? -1 : std::atoi(e) > 2 ? 1 : std::atoi(e);
+  if (const char* e = std::getenv("RSORT_HYBRID")) c->hybrid_mode = std::atoi(e) < 0 ? -1 : std::atoi(e) > 3 ? 1 : std::atoi(e);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->cus = prop.multiProcessorCount;
@@ -1395,7 +1424,7 @@ int rs_ctx_set_precheck(rs_ctx* c, int enabled) {
 
 int rs_ctx_set_hybrid(rs_ctx* c, int mode) {
   if (!c) return RS_ERR_ARG;
-  if (mode < -1 || mode > 2) return fail(c, RS_ERR_ARG, "hybrid mode must be -1 (per sort), 0 (never), 1 (16-bit groups whenever the shape allows) or 2 (narrow form whenever it does)");
+  if (mode < -1 || mode > 3) return fail(c, RS_ERR_ARG, "hybrid mode must be -1 (per sort), 0 (never), 1 (16-bit groups whenever the shape allows), 2 (narrow form whenever it does) or 3 (prefixed form whenever it does)");
   c->hybrid_mode = mode;
   return RS_OK;
 }

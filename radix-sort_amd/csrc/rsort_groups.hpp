@@ -33,6 +33,7 @@ struct GroupArgs {
   unsigned groups;
   int low_bits;                // bits still to sort, 1..16 (values are staged as 16-bit words)
   uint64_t fmask_out, smask_out;   // inverse key transform, applied in the store
+  uint64_t top_or;             // key bits above the group's number that every key shares (prefixed form; 16-bit staging kernel: put back with it), else 0
   unsigned* big_list;          // groups too large for the LDS window: [0] = how many, [1..] = group numbers
   unsigned big_cap;            // room in big_list (entries)
   unsigned max_vec;            // groups whose window has more 16-byte vectors than this are left to the big-group kernel (<= BLOCK * MAXV)
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
     }
     return;
   }
-  const K top = static_cast<K>(g) << a.low_bits;
+  const K top = (static_cast<K>(g) << a.low_bits) | static_cast<K>(a.top_or);
   const K fmo = static_cast<K>(a.fmask_out), smo = static_cast<K>(a.smask_out);
   const unsigned it = (nvec + BLOCK - 1) / BLOCK;
   switch (it) {      // (one instantiation per vector count: a group of 16384 +- 130 keys takes 8 or 9 of 512 threads' vectors)

@@ -46,18 +46,28 @@ DIGIT = 8
 # ---------------------------------------------------------------------------------------------
 # split planning (pure numpy on small tables; identical on every rank)
 # ---------------------------------------------------------------------------------------------
+def snap_tolerance(total: int, world: int) -> int:
+    """Keys a boundary may miss its quantile by for the sake of a top-digit edge: a quarter of a per cent of a rank's share.
+    A boundary on a top-digit edge costs no second-digit pass over its bucket, and ranks whose ranges begin and end on
+    such edges hold keys that share their leading bits (G = 8, uniform keys: three of them), which is what the local
+    sort's prefixed hybrid form needs (rsort_api.hip)."""
+    return total // world // 400
+
+
 def boundary_buckets(level1_all: np.ndarray, world: int):
-    """Top-digit buckets that contain an interior quantile r*N/G strictly inside them.
+    """Top-digit buckets that contain an interior quantile r*N/G inside them, further than snap_tolerance from both edges
+    (plan_splits puts a boundary of an unrefined bucket on the nearer edge).
 
     level1_all: [G, 256] per-rank counts of the top digit."""
     g = level1_all.sum(axis=0).astype(np.int64)
     total = int(g.sum())
     cum = np.cumsum(g)
+    tol = snap_tolerance(total, world)
     out = []
     for r in range(1, world):
         q = (r * total) // world
         b = int(np.searchsorted(cum, q, side="right"))
-        if b < 256 and (cum[b] - g[b]) < q < cum[b]:      # strictly inside bucket b
+        if b < 256 and (cum[b] - g[b]) + tol < q < cum[b] - tol:      # inside bucket b, away from its edges
             out.append(b)
     return sorted(set(out))
 

@@ -28,8 +28,28 @@ def test_plan_is_balanced_and_consistent():
     for r in range(world):
         want = int(((allk >> 16) >= split[r]).sum() - ((allk >> 16) >= split[r + 1]).sum())
         assert counts[:, r].sum() == want
-        assert abs(want - allk.size / world) <= allk.size / 65536 * 4 + 64      # 16-bit resolution
+        # 16-bit resolution, and a boundary may sit on a top-digit edge up to snap_tolerance keys from its quantile (each rank has two)
+        assert abs(want - allk.size / world) <= allk.size / 65536 * 4 + 64 + 2 * rsd.snap_tolerance(allk.size, world)
     assert counts.sum() == allk.size and np.array_equal(counts.sum(axis=1), [k.size for k in keys])
+
+
+def test_boundaries_snap_to_top_digit_edges_when_that_is_free():
+    """Uniform keys over 8 ranks: every quantile lies within a few keys of a top-digit edge, so no bucket is refined, the
+    boundaries are multiples of 256 * 32 and every rank's keys share their three leading bits (the local sort's prefixed
+    hybrid form lives on that); a distribution whose quantiles fall inside buckets is refined as before."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    world = 8
+    keys = [rng.integers(0, 1 << 32, 400_000, dtype=np.uint32) for _ in range(world)]
+    l1 = np.stack([np.bincount(k >> 24, minlength=256) for k in keys]).astype(np.int64)
+    assert rsd.boundary_buckets(l1, world) == []
+    split = rsd.plan_splits(l1, {}, world)
+    assert list(split) == [r * 8192 for r in range(world + 1)]
+    counts = rsd.exchange_counts(l1, {}, split, world)
+    share = counts.sum(axis=0)
+    assert share.max() / share.mean() <= 1.01
+    skew = [k // np.uint32(3) + np.uint32(1 << 29) for k in keys]              # a third of the range: quantiles at 32 + 10.67 r, away from the edges
+    l1s = np.stack([np.bincount(k >> 24, minlength=256) for k in skew]).astype(np.int64)
+    assert len(rsd.boundary_buckets(l1s, world)) >= 4
 
 
 def test_plan_degenerate_inputs():

@@ -178,6 +178,44 @@ def test_narrow_hybrid_prefixes(engine):
         engine.set_precheck(True)
 
 
+def test_prefixed_hybrid(engine, oracle):
+    """Keys that share their leading t bits (a multi-GPU rank's keys after the exchange): two sweeps on the 16 bits below
+    the prefix, groups finished in LDS, the prefix put back.  Every t, 4- and 8-byte keys, the transforms; a prefix the
+    sample believes in but one key breaks (the histogram notices: the plain loop); skewed bits below the prefix."""
+    rng = np.random.Generator(np.random.PCG64(43))
+    engine.set_precheck(False)
+    engine.set_hybrid(3)
+    try:
+        n = 4_400_001
+        for dtype, bits in ((np.uint32, 32), (np.uint64, 64)):
+            full = rng.integers(0, 1 << 63, n, dtype=np.uint64).astype(dtype) if bits == 32 else rng.integers(0, 1 << 64, n, dtype=np.uint64)
+            for t in range(1, 8):
+                prefix = dtype(int(rng.integers(0, 1 << t)) << (bits - t))
+                v = (full >> dtype(t)) | prefix
+                got, _ = _sort_on_device(engine, v, 0, t & 1)
+                assert got.tobytes() == np.sort(v).tobytes(), (dtype, t)
+                assert engine.lib.rs_debug_last_hybrid(engine.h) == 3, (dtype, t)
+            v = (full >> dtype(3)) | dtype(5 << (bits - 3))
+            v[n // 2] = dtype(1)                                       # one key outside the prefix, not in the sample
+            got, _ = _sort_on_device(engine, v, 0)
+            assert got.tobytes() == np.sort(v).tobytes() and engine.lib.rs_debug_last_hybrid(engine.h) == 0, dtype
+            v = ((full >> dtype(3)) | dtype(2 << (bits - 3))) & ~dtype(0x3F << (bits - 11))      # eight bits below the prefix of four values
+            got, _ = _sort_on_device(engine, v, 0)
+            assert got.tobytes() == np.sort(v).tobytes(), dtype
+        for name in ("i32", "f32", "i64", "f64"):
+            dt, kb, xf = shapes.KEY_TYPES[name]
+            v = shapes.generate(name, n, "randomized")
+            if name[0] == "i":
+                v = (v >> 2) + (1 << (kb * 8 - 3))                    # positive, two leading bits shared
+            else:
+                v = np.abs(v)                                          # sign bit shared (NaN payloads and all)
+            got, _ = _sort_on_device(engine, v, xf)
+            assert got.tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), name
+    finally:
+        engine.set_hybrid(-1)
+        engine.set_precheck(True)
+
+
 def _sort_pairs_on_device(engine, v, xf, offset=0):
     """(v, 0..n-1) through rs_sort_pairs_device, 4-byte payload: (sorted keys, payload = the stable permutation, took the hybrid form)."""
     import torch

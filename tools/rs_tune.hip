@@ -1,7 +1,7 @@
 // rs_tune.hip -- developer harness: times one build of librsort_hip.so (path given) on synthetic
 // keys, device-resident, and verifies order on the device.  Not part of the product or the tests.
 //   hipcc -O2 --offload-arch=gfx950 tools/rs_tune.hip -o tools/rs_tune -ldl
-//   tools/rs_tune <lib.so> <key_bytes> <log2n|n> <shape: random|sorted|reverse|nearly|dups> [iters] [value_bytes]
+//   tools/rs_tune <lib.so> <key_bytes> <log2n|n> <shape: random|sorted|reverse|nearly|dups|ramp32|prefix3> [iters] [value_bytes]
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -28,6 +28,7 @@ template <typename K> __global__ void gen(K* k, uint64_t n, int shape) {
     if (shape == 0) v = mix(i);
     else if (shape == 4) v = mix(mix(i) & 255);
     else if (shape == 5) v = (i >> 5) * (step << 5);      // sorted, every value 32 times (what a float ramp looks like)
+    else if (shape == 6) v = ((mix(i) & umax) >> 3) | (5ull << (sizeof(K) * 8 - 3));   // random below a shared 3-bit prefix (a rank of 8 after the exchange)
     else {
       uint64_t j = i;
       if (shape == 2) j = n - 1 - i;
@@ -59,7 +60,7 @@ int main(int argc, char** argv) {
   auto f_err = (const char* (*)(const rs_ctx*))dlsym(h, "rs_last_error");
   int kb = atoi(argv[2]);
   uint64_t n = strtoull(argv[3], 0, 10); if (n <= 40) n = 1ull << n;
-  int shape = !strcmp(argv[4], "random") ? 0 : !strcmp(argv[4], "sorted") ? 1 : !strcmp(argv[4], "reverse") ? 2 : !strcmp(argv[4], "nearly") ? 3 : !strcmp(argv[4], "ramp32") ? 5 : 4;
+  int shape = !strcmp(argv[4], "random") ? 0 : !strcmp(argv[4], "sorted") ? 1 : !strcmp(argv[4], "reverse") ? 2 : !strcmp(argv[4], "nearly") ? 3 : !strcmp(argv[4], "ramp32") ? 5 : !strcmp(argv[4], "prefix3") ? 6 : 4;
   int iters = argc > 5 ? atoi(argv[5]) : 5;
   int vb = argc > 6 ? atoi(argv[6]) : 0;
   rs_ctx* c = nullptr;

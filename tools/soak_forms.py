@@ -15,7 +15,7 @@ eng = rs.Engine(0, stream=torch.cuda.current_stream().cuda_stream)
 eng.set_precheck(False)
 t_end = time.time() + budget
 done = fails = 0
-forms = {"hybrid": 0, "narrow": 0, "distinct": 0, "lsd": 0}
+forms = {"hybrid": 0, "narrow": 0, "prefixed": 0, "distinct": 0, "lsd": 0}
 
 
 def rand_bits(n, kb):
@@ -31,7 +31,7 @@ while time.time() < t_end:
     n = int(rng.integers(4_300_000, 8_000_000 if limit else 40_000_000))
     dt = torch.int32 if kb == 4 else torch.int64
     bits = kb * 8
-    kind = int(rng.integers(7))
+    kind = int(rng.integers(8))
     keys = rand_bits(n, kb)
     if kind == 1:                                            # few distinct keys (around the table's limit of 1024, too)
         pool = rand_bits(int(rng.choice([1, 2, 7, 256, 1000, 1024, 1025, 1500, 5000])), kb)
@@ -52,7 +52,12 @@ while time.time() < t_end:
         m = n // 40
         a = torch.randint(0, n, (m,), device="cuda"); b = torch.randint(0, n, (m,), device="cuda")
         tmp = keys[a].clone(); keys[a] = keys[b]; keys[b] = tmp
-    hybrid = int(rng.choice([-1, -1, 1, 1, 2]))               # as shipped / 16-bit groups forced / narrow form forced
+    elif kind == 7:                                          # leading bits shared by every key (a multi-GPU rank's keys): the prefixed form
+        t = int(rng.integers(1, 9))
+        keys = ((keys.to(torch.int64) & ((1 << (bits - t)) - 1)) | (int(rng.integers(0, 1 << t)) << (bits - t))).to(dt)
+        if rng.integers(5) == 0:
+            keys[int(rng.integers(0, n))] = 3                 # ... but for one key
+    hybrid = int(rng.choice([-1, -1, 1, 1, 2, 3, 3]))         # as shipped / 16-bit groups / narrow form / prefixed form forced where the shape allows
     eng.set_hybrid(hybrid)
     eng.lib.rs_debug_set_group_limit(eng.h, limit)
     sign = -(1 << (bits - 1))
@@ -66,7 +71,7 @@ while time.time() < t_end:
         eng.sort_keys_(keys, xf)
     eng.synchronize()
     took = int(eng.lib.rs_debug_last_hybrid(eng.h))
-    forms["hybrid" if took == 1 else "narrow" if took == 2 else "distinct" if eng.lib.rs_debug_last_distinct(eng.h) else "lsd"] += 1
+    forms["hybrid" if took == 1 else "narrow" if took == 2 else "prefixed" if took == 3 else "distinct" if eng.lib.rs_debug_last_distinct(eng.h) else "lsd"] += 1
     order = (lambda k: k if xf == 1 else (k ^ sign if xf == 0 else torch.where(k < 0, ~k ^ sign, k)))
     want, idx = torch.sort(order(src), stable=True)
     ok = bool((order(keys) == want).all().item())
