@@ -87,7 +87,8 @@ int rs_ctx_set_tile_order(rs_ctx* ctx, int per_xcd);
  * between about 2*10^6 and 10^8 keys a narrow one: sweeps on the top 9 to 15 bits, whole keys of every group finished in LDS.
  *   mode -1 (default): chosen per sort, from its size and its digit counts (groups must fit the LDS window);
  *   mode  0: never;   mode 1: groups of equal top 16 bits whenever the key shape allows it, at any size and distribution;
- *   mode  2: the narrow form whenever the key shape allows it (1 and 2: tests, A/B timing).
+ *   mode  2: the narrow form whenever the key shape allows it;   mode 3: the prefixed form (keys that share their leading
+ *            1 to 7 bits: sweeps on the 16 bits below the prefix) whenever it does (1, 2 and 3: tests, A/B timing).
  * The environment variable RSORT_HYBRID gives the default of new contexts.  No counterpart in the reference. */
 int rs_ctx_set_hybrid(rs_ctx* ctx, int mode);
 

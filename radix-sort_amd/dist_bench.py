@@ -140,6 +140,7 @@ def _run_type(args, name, rank, world, dev):
                       "count_kept": s[0] == s[2], "checksum_kept": s[1] == s[3]},
            "keys_per_rank_after_exchange": sizes.cpu().tolist(),
            "phase_ms_max_over_ranks": phase_ms,          # from the extra, synchronised sort: where a step's time goes
+           "local_sort_form_rank0": {0: "lsd", 1: "hybrid", 2: "narrow hybrid", 3: "prefixed hybrid"}.get(int(eng.lib.rs_debug_last_hybrid(eng.h)), "?"),
            "stages": stages,                              # RSORT_DIST_STAGES (1 = unpipelined)
            "stage_done_ms_rank0": st.get("stage_done_ms"),   # pipelined form: when each stage was exchanged and sorted, from the first post
            "peak_device_bytes_max_over_ranks": {"torch_tensors": int(mem[0].item()), "device_in_use_after_sort": int(mem[1].item())},
