@@ -997,7 +997,10 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     } else {
       hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
       ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWideGroupCap) : static_cast<unsigned>(kWideGroupCap);   // (keys, for this kernel)
-      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(narrow_bits ? 256u << narrow_bits : kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
+      if (prefix_bits)     // (41 to 47 low bits: passes from bit 24 up, so that the prefix the fix-up works below stays 17 bits or more)
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems, 24>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
+      else
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(narrow_bits ? 256u << narrow_bits : kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint64_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     }

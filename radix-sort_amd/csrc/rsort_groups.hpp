@@ -369,7 +369,10 @@ template <typename K> constexpr int group_fix_top(int low) {
 // V = NoVal: keys only.  V = a 4-byte payload (a.vals): the stable pair form -- every pass and the fix-up keep equal keys in
 // their order, the payload rides through the staging area beside its key; groups beyond the (smaller) window are only
 // counted in big_list[0] and the host sorts the whole array again, every pass (the big-group kernel is keys only).
-template <typename K, typename V, int BLOCK, int ITEMS>
+// TOP_FROM: where the groups' passes start when it is not the default (bit 32 for 8-byte keys).  The prefixed form leaves
+// 41 to 47 low bits: from bit 32 that is a prefix of 9 to 15 bits and runs of two or three keys for the fix-up (11.1 ms at
+// N = 2^30); from bit 24, one pass more and runs of one key.
+template <typename K, typename V, int BLOCK, int ITEMS, int TOP_FROM = -1>
 __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
   __shared__ TileSortSmem<K, V, BLOCK, ITEMS> s;
   constexpr bool HAS_VAL = !__is_same(V, NoVal);
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
   if constexpr (HAS_VAL) gv = static_cast<V*>(a.vals) + start;
   // (8-byte keys: passes from bit 32 up -- 16 bits of prefix for the 48 low bits of the 16-bit-group form, up to 23 for the
   // narrow form's 55 -- then the fix-up; 4-byte keys: passes over all the low bits)
-  group_tile_sort<K, V, BLOCK, ITEMS, group_fix_top<K>((static_cast<int>(sizeof(K)) - 2) * 8)>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, gv, len,
+  group_tile_sort<K, V, BLOCK, ITEMS, (TOP_FROM >= 0 ? TOP_FROM : group_fix_top<K>((static_cast<int>(sizeof(K)) - 2) * 8))>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, gv, len,
                                                                                                static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), a.low_bits);
 }
 
