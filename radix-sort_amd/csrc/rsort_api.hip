@@ -110,6 +110,14 @@ constexpr int kSmallGroupBlock = 256;          // 4-byte keys, groups of at most
 constexpr size_t kSmallGroupMeanMax = 6500;    // mean group size below which the four-wave workgroups sort the groups (n below 4.26e8; measured 1.3e8 / 2.7e8 / 4e8 keys: 1030 / 1747 / 2525 against 1164 / 1913 / 2681 us)
 constexpr int kWidePairGroupItems = 12;   // 8-byte keys with a 4-byte payload: 1024 x 12 = 12288 pairs = 144 KB
 constexpr size_t kWidePairGroupCap = size_t(1024) * kWidePairGroupItems;
+// 4-byte keys with a 4-byte payload: the same kernel in smaller workgroups, so that several share a CU and one's load and
+// store hide behind the others' passes -- 512 x 17 = 8704 pairs = 78 KB with the counters, two to a CU (2^29 pairs: group sort
+// 2.07 ms, whole sort 7.66 -> 6.16 ms; one workgroup of 1024 x 12 per CU: 3.4 ms, no gain over the two sweeps it replaces);
+// when the largest group fits 256 x 17 = 4352 pairs, four to a CU (1 / 1.34 / 2 * 10^8 pairs: 1.50 / 1.80 / 2.49 ms against
+// 1.68 / 2.12 / 2.74 with 512 threads and 1.61 / 1.96 / 2.97 for the four-pass loop; 6.7 * 10^7: 1.11 against 1.02, hence the threshold)
+constexpr int kPair32Block = 512, kPair32SmallBlock = 256, kPair32Items = 17;
+constexpr size_t kPair32Cap = size_t(kPair32Block) * kPair32Items, kPair32SmallCap = size_t(kPair32SmallBlock) * kPair32Items;
+constexpr size_t kHybridMinPairs = 90000000;
 constexpr unsigned kGroupCount = 65536;
 constexpr size_t kGroupsBytes = (size_t(kGroupCount) + 1 + kGroupCount + 1) * sizeof(unsigned);   // start table + list of oversize groups
 
@@ -811,11 +819,12 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   const int hybrid_env = c->hybrid_mode;
   bool hybrid = false;
   const int top_lo = prefix_bits ? 0 : passes - 2, top_hi = prefix_bits ? 1 : passes - 1;   // the two swept digits (whole-key sorts: passes = key bytes; the narrow and the prefixed form: 0 and 1)
-  // Pair form (8-byte keys, 4-byte payload; stable): the same two sweeps, the wide group kernel with the payload beside the
+  // Pair form (4- or 8-byte keys, 4-byte payload; stable): the same two sweeps, the wide group kernel with the payload beside the
   // keys and a smaller window; a group beyond it sends the array -- as the sweeps left it: a stable rearrangement of the
   // input, keys transformed -- through the plain loop instead (there is no big-group kernel for pairs).
-  const bool pair_form = value_bytes == 4 && key_bytes == 8 && vals != nullptr;
-  const size_t group_cap = pair_form ? kWidePairGroupCap : key_bytes == 4 ? (n / kGroupCount < small_group_mean_max() ? size_t(kSmallGroupBlock) * kGroupMaxVec * 4 - 3 : kGroupCap) : kWideGroupCap;
+  const bool pair_form = value_bytes == 4 && (key_bytes == 8 || key_bytes == 4) && vals != nullptr;
+  const size_t pair_cap = key_bytes == 4 ? kPair32Cap : kWidePairGroupCap;
+  const size_t group_cap = pair_form ? pair_cap : key_bytes == 4 ? (n / kGroupCount < small_group_mean_max() ? size_t(kSmallGroupBlock) * kGroupMaxVec * 4 - 3 : kGroupCap) : kWideGroupCap;
   if (hybrid_env != 0 && hybrid_env != 2 && hybrid_env != 3 && !narrow_bits && !prefix_bits && !ws && !mid && !(sweep_chain ? wide_chain : wide) && !forward_done && (value_bytes == 0 || pair_form) && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
       end_bit == key_bytes * 8 && n_live == key_bytes && n < (size_t(1) << 32) && c->rank_by_lds_atomic &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
@@ -826,7 +835,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       for (int p = 0; p < key_bytes; ++p)
         for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
       const double bound = static_cast<double>(mx[top_hi]) * static_cast<double>(mx[top_lo]) / static_cast<double>(n);   // largest group if the top digits are independent
-      hybrid = n >= (key_bytes == 4 ? kHybridMinKeys : pair_form ? kHybridMinPairsWide : kHybridMinKeysWide) && bound <= (key_bytes == 8 && !pair_form ? 0.97 : 0.95) * group_cap;
+      hybrid = n >= (pair_form ? (key_bytes == 4 ? kHybridMinPairs : kHybridMinPairsWide) : key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide) && bound <= (key_bytes == 8 && !pair_form ? 0.97 : 0.95) * group_cap;
       for (int p = 0; p < top_lo; ++p) hybrid = hybrid && mx[p] <= n / 16;
     }
   }
@@ -953,13 +962,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     ba.keys = keys; ba.alt = alt_keys; ba.start = start; ba.big_list = big_list; ba.big_cap = kGroupCount; ba.low_bits = ga.low_bits;
     ba.fmask_out = fmask; ba.smask_out = smask;
     ba.n = static_cast<unsigned>(n); ba.error_flag = error_flag;
-    if (key_bytes == 4 && narrow_bits) {    // whole keys in LDS (the low part is wider than the 16-bit staging of the kernel below)
+    if (key_bytes == 4 && narrow_bits && !pair_form) {    // whole keys in LDS (the low part is wider than the 16-bit staging of the kernel below)
       hipLaunchKernelGGL(rsk::group_table_kernel<uint32_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
       ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWideGroupCap) : static_cast<unsigned>(kWideGroupCap);   // (keys, for this kernel)
       hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(256u << narrow_bits), dim3(kWideGroupBlock), 0, s, ga);
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
-    } else if (key_bytes == 4) {
+    } else if (key_bytes == 4 && !pair_form) {
       hipLaunchKernelGGL(rsk::group_table_kernel<uint32_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
       // Small groups (sorts of some 10^7 to 10^8 keys: a thousand keys per group) go to workgroups of four waves, six of
       // which share a CU, instead of leaving most of 512 threads idle; the few groups beyond their window (10237 keys) to the
@@ -974,9 +983,10 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     } else if (pair_form) {
-      hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
+      if (key_bytes == 4) hipLaunchKernelGGL(rsk::group_table_kernel<uint32_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
+      else hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
       ga.vals = vals;
-      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWidePairGroupCap) : static_cast<unsigned>(kWidePairGroupCap);
+      ga.max_vec = c->group_max_vec ? static_cast<unsigned>(std::min<size_t>(size_t(c->group_max_vec) * 4u, pair_cap)) : static_cast<unsigned>(pair_cap);
       // the largest group, before anything is sorted: big_list[0] doubles as the word the maximum is gathered in
       hipLaunchKernelGGL(rsk::group_max_kernel, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, static_cast<const unsigned*>(start), big_list);
       unsigned largest = 0;
@@ -992,7 +1002,12 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
         return rc;
       }
       RS_HIP(c, hipMemsetAsync(big_list, 0, sizeof(unsigned), s));
-      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, uint32_t, kWideGroupBlock, kWidePairGroupItems>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
+      if (key_bytes == 4 && largest <= kPair32SmallCap)
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, uint32_t, kPair32SmallBlock, kPair32Items>), dim3(kGroupCount), dim3(kPair32SmallBlock), 0, s, ga);
+      else if (key_bytes == 4)
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, uint32_t, kPair32Block, kPair32Items>), dim3(kGroupCount), dim3(kPair32Block), 0, s, ga);
+      else
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, uint32_t, kWideGroupBlock, kWidePairGroupItems>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     } else {
       hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);

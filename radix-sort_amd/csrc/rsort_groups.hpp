@@ -369,6 +369,8 @@ template <typename K> constexpr int group_fix_top(int low) {
 // V = NoVal: keys only.  V = a 4-byte payload (a.vals): the stable pair form -- every pass and the fix-up keep equal keys in
 // their order, the payload rides through the staging area beside its key; groups beyond the (smaller) window are only
 // counted in big_list[0] and the host sorts the whole array again, every pass (the big-group kernel is keys only).
+// Pairs of 4-byte keys run it in workgroups of 512 or 256 threads x 17 pairs (two or four to a CU: two plain passes over
+// the 16 low bits, and another workgroup's passes to hide the load and the store behind).
 // TOP_FROM: where the groups' passes start when it is not the default (bit 32 for 8-byte keys).  The prefixed form leaves
 // 41 to 47 low bits: from bit 32 that is a prefix of 9 to 15 bits and runs of two or three keys for the fix-up (11.1 ms at
 // N = 2^30); from bit 24, one pass more and runs of one key.

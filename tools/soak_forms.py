@@ -1,5 +1,5 @@
 """Soak of the round-3 forms of large sorts -- hybrid (two sweeps + in-LDS group sort, forced on at these sizes), few
-distinct keys, the groups' prefix passes + fix-up and its fall-back, oversize groups, stable pairs of 8-byte keys and a 4-byte
+distinct keys, the groups' prefix passes + fix-up and its fall-back, oversize groups, stable pairs of 4- and 8-byte keys and a 4-byte
 payload -- on one context, random size, width, transform and key distribution, every result compared element by element with
 torch's (stable) sort of the same keys.
 python tools/soak_forms.py [seconds]"""
@@ -62,7 +62,7 @@ while time.time() < t_end:
     eng.lib.rs_debug_set_group_limit(eng.h, limit)
     sign = -(1 << (bits - 1))
     src = keys.clone()
-    pairs = kb == 8 and int(rng.integers(3)) == 0
+    pairs = int(rng.integers(3)) == 0                        # (4-byte keys: windows of 4352 and 8704 pairs, the plain loop beyond)
     vals = torch.arange(n, dtype=torch.int32, device="cuda") if pairs else None
     torch.cuda.synchronize()
     if pairs:
