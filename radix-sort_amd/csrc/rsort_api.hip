@@ -86,12 +86,12 @@ constexpr size_t kSmallDescLimit = size_t(1) << 30;   // 30 value bits in a 4-by
 // rs_ctx_set_tile_order(ctx, 0) turns it off for callers that do run such sorts concurrently on one device.
 constexpr size_t kPerXcdMinTiles = 1024;
 constexpr size_t kHybridMinKeys = 64000000;    // hybrid form of 4-byte key sorts from here on (four-wave group kernel; 2^26 keys 655 against 674 us, 10^8 875 against 970; 2^25 429 against 385 -- below, the fixed cost of 65536 workgroups outweighs the two sweeps saved)
-constexpr size_t kHybridMinKeysWide = 100000000;   // the same for 8-byte keys (two LDS passes + fix-up per group; 2^27 keys: 3.21 against 3.90 ms, 2^28: 5.0 against 7.6; 2^26: 2.36 against 2.06)
+constexpr size_t kHybridMinKeysWide = 120000000;   // the same for 8-byte keys (two LDS passes + fix-up per group; 2^27 keys: 3.21 against 3.90 ms, 2^28: 5.0 against 7.6; 2^26: 2.36 against 2.06)
 // Narrow hybrid form (sort_device): 8-byte keys from the end of the mid-size regime up to kHybridMinKeysWide -- 5 / 16.7 / 67 M keys
 // 219 / 404 / 1358 us against 342 / 596 / 2075 us with eight passes.  4-byte keys: never by itself (whole keys in LDS, three
 // LDS passes: 16.7 M keys 308 against 241 us with four passes); rs_ctx_set_hybrid(2) forces it for tests.
 constexpr size_t kNarrowMinKeys = kHybridMinKeys, kNarrowMinKeysWide = 0;
-constexpr size_t kHybridMinPairsWide = 64000000;    // and with a 4-byte payload (2^26 pairs: 2.71 against 2.88 ms, 2^27: 3.9 against 5.7, 2^28: 6.5 against 11.5)
+constexpr size_t kHybridMinPairsWide = 14000000;    // and with a 4-byte payload (1 / 2 / 3 / 4.5 * 10^7 pairs: 0.53 / 0.77 / 0.95 / 1.24 against 0.51 / 1.03 / 1.55 / 2.07 ms; 2^26: 1.64 against 2.88, 2^28: 5.2 against 11.5)
 constexpr size_t kAlwaysSweepTiles = 256;   // up to here (4 M four-byte keys) neither pass skipping nor the order pre-check is worth a host synchronisation
 
 // Hybrid sort of 4-byte keys (rsort_groups.hpp): two sweeps on the top digits, then every group of equal top 16 bits is
@@ -118,8 +118,13 @@ constexpr size_t kWidePairGroupCap = size_t(1024) * kWidePairGroupItems;
 constexpr int kPair32Block = 512, kPair32SmallBlock = 256, kPair32Items = 17;
 constexpr size_t kPair32Cap = size_t(kPair32Block) * kPair32Items, kPair32SmallCap = size_t(kPair32SmallBlock) * kPair32Items;
 constexpr size_t kHybridMinPairs = 90000000;
+// 8-byte groups well inside smaller windows run in smaller workgroups, several to a CU (one's load and store behind the
+// others' passes): 256 threads x 17 = 4352 keys, four per CU; 512 x 17 = 8704, two per CU.  The narrow form aims its groups at
+// the smallest window.  (2^26 / 10^8 / 2 * 10^8 / 2^28 / 4 * 10^8 keys: 1.34 / 2.88 / 3.98 / 5.21 / 6.91 -> 1.21 / 1.65 / 2.79 / 4.10 / 5.68 ms)
+constexpr double kNarrowGroupTarget = 3700;
 constexpr unsigned kGroupCount = 65536;
-constexpr size_t kGroupsBytes = (size_t(kGroupCount) + 1 + kGroupCount + 1) * sizeof(unsigned);   // start table + list of oversize groups
+constexpr size_t kGroupsBytes = (size_t(kGroupCount) + 1) * 3 * sizeof(unsigned);   // start table + list of oversize groups + list of the groups beyond the small workgroups' window
+constexpr size_t kGroupCheckMinKeys = 500000000;   // sorts from here on look at their groups' real sizes before the LDS finish (one read-back: 40-60 us with the launches it holds up)
 
 struct DevBuf {
   void* p = nullptr;
@@ -494,6 +499,22 @@ int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t f
   return RS_OK;
 }
 
+size_t hybrid_min_keys_wide() {     // RSORT_HYBRID_MIN_WIDE (A/B timing): 8-byte keys-only sorts below this take the narrow form, from it on groups of equal top 16 bits
+  static const size_t v = [] { const char* e = std::getenv("RSORT_HYBRID_MIN_WIDE"); return e && e[0] ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kHybridMinKeysWide; }();
+  return v;
+}
+double narrow_group_target() {     // RSORT_NARROW_GROUP (A/B timing): keys per group the narrow form aims at
+  static const double v = [] { const char* e = std::getenv("RSORT_NARROW_GROUP"); return e && e[0] ? std::strtod(e, nullptr) : kNarrowGroupTarget; }();
+  return v;
+}
+int wide_small_blocks() {     // RSORT_WIDE_SMALL=0 (A/B timing): 8-byte groups always in workgroups of 1024 threads
+  static const int v = [] { const char* e = std::getenv("RSORT_WIDE_SMALL"); return e && e[0] ? std::atoi(e) : 1; }();
+  return v;
+}
+size_t group_check_min_keys() {     // RSORT_GROUP_CHECK_MIN (A/B timing)
+  static const size_t v = [] { const char* e = std::getenv("RSORT_GROUP_CHECK_MIN"); return e && e[0] ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : kGroupCheckMinKeys; }();
+  return v;
+}
 size_t small_group_mean_max() {     // RSORT_SMALL_GROUP_MEAN (A/B timing): mean group size below which the four-wave workgroups sort the groups
   static const size_t v = [] { const char* e = std::getenv("RSORT_SMALL_GROUP_MEAN"); return e ? static_cast<size_t>(std::atol(e)) : kSmallGroupMeanMax; }();
   return v;
@@ -653,16 +674,16 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   }
 
   // Narrow hybrid form (keys-only sorts between the mid-size regime and the sizes where 65536 groups pay): the same two
-  // sweeps and in-LDS finish, but on the top 8 + b bits only, b chosen so that the 2^(8+b) groups hold about 0.7 windows
-  // each -- the sort is then a sort on the bit range [sort_begin, end_bit) (two digits: 8 bits and, on top, b bits) followed
+  // sweeps and in-LDS finish, but on the top 8 + b bits only, b chosen so that the 2^(8+b) groups hold at most kNarrowGroupTarget keys
+  // each (the window of the smallest workgroups of the group kernel, four of which share a CU) -- the sort is then a sort on the bit range [sort_begin, end_bit) (two digits: 8 bits and, on top, b bits) followed
   // by the wide group kernel on the bits below.  Decided from n alone, before the histogram (which then covers only the two
   // swept digits); whether the groups really fit is known from those counts, and the plain loop takes over when they do not.
   int sort_begin = begin_bit, narrow_bits = 0;
   if ((c->hybrid_mode == -1 || c->hybrid_mode == 2) && !ws && !mid && !wide && !forward_done && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) &&
       begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic && (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0 &&
-      n < (key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide) && (c->hybrid_mode == 2 || n >= (key_bytes == 4 ? kNarrowMinKeys : kNarrowMinKeysWide))) {
+      n < (key_bytes == 4 ? kHybridMinKeys : hybrid_min_keys_wide()) && (c->hybrid_mode == 2 || n >= (key_bytes == 4 ? kNarrowMinKeys : kNarrowMinKeysWide))) {
     int g = 9;
-    while (g < 16 && static_cast<double>(n) / static_cast<double>(size_t(1) << g) > 0.7 * kWideGroupCap) ++g;
+    while (g < 16 && static_cast<double>(n) / static_cast<double>(size_t(1) << g) > narrow_group_target()) ++g;
     // (the sample of the few-distinct probe, when it ran: bits that are the same in every sampled key.  The top g bits must
     // all differ somewhere, or the groups cannot be balanced -- 8-byte keys that hold small integers -- and the plain loop,
     // which skips constant digits, is the better start.  A hint only: the histogram below still decides.)
@@ -683,7 +704,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   if (!narrow_bits && (c->hybrid_mode == -1 || c->hybrid_mode == 3) && span[2] && !ws && !mid && !forward_done && value_bytes == 0 &&
       (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0 && n < (size_t(1) << 32) &&
-      (c->hybrid_mode == 3 || n >= (key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide))) {
+      (c->hybrid_mode == 3 || n >= (key_bytes == 4 ? kHybridMinKeys : hybrid_min_keys_wide()))) {
     const unsigned long long vary = (span[0] ^ span[1]) & all;
     if (vary) {
       const int t = end_bit - (64 - __builtin_clzll(vary));       // leading bits the sampled keys share
@@ -818,6 +839,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // rs_ctx_set_hybrid / RSORT_HYBRID: 0 never, 1 whenever the shape allows it (tests: any size, any distribution).
   const int hybrid_env = c->hybrid_mode;
   bool hybrid = false;
+  double group_bound = 0;          // the largest group, as the digit counts bound it (0: not known)
   const int top_lo = prefix_bits ? 0 : passes - 2, top_hi = prefix_bits ? 1 : passes - 1;   // the two swept digits (whole-key sorts: passes = key bytes; the narrow and the prefixed form: 0 and 1)
   // Pair form (4- or 8-byte keys, 4-byte payload; stable): the same two sweeps, the wide group kernel with the payload beside the
   // keys and a smaller window; a group beyond it sends the array -- as the sweeps left it: a stable rearrangement of the
@@ -828,14 +850,15 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   if (hybrid_env != 0 && hybrid_env != 2 && hybrid_env != 3 && !narrow_bits && !prefix_bits && !ws && !mid && !(sweep_chain ? wide_chain : wide) && !forward_done && (value_bytes == 0 || pair_form) && (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 &&
       end_bit == key_bytes * 8 && n_live == key_bytes && n < (size_t(1) << 32) && c->rank_by_lds_atomic &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0) {
+    unsigned long long mx[kMaxPasses] = {};
+    for (int p = 0; p < key_bytes; ++p)
+      for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
+    const double bound = static_cast<double>(mx[top_hi]) * static_cast<double>(mx[top_lo]) / static_cast<double>(n);   // largest group if the top digits are independent
+    group_bound = bound;
     if (hybrid_env == 1) {
       hybrid = true;
     } else {
-      unsigned long long mx[kMaxPasses] = {};
-      for (int p = 0; p < key_bytes; ++p)
-        for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
-      const double bound = static_cast<double>(mx[top_hi]) * static_cast<double>(mx[top_lo]) / static_cast<double>(n);   // largest group if the top digits are independent
-      hybrid = n >= (pair_form ? (key_bytes == 4 ? kHybridMinPairs : kHybridMinPairsWide) : key_bytes == 4 ? kHybridMinKeys : kHybridMinKeysWide) && bound <= (key_bytes == 8 && !pair_form ? 0.97 : 0.95) * group_cap;
+      hybrid = n >= (pair_form ? (key_bytes == 4 ? kHybridMinPairs : kHybridMinPairsWide) : key_bytes == 4 ? kHybridMinKeys : hybrid_min_keys_wide()) && bound <= (key_bytes == 8 && !pair_form ? 0.97 : 0.95) * group_cap;
       for (int p = 0; p < top_lo; ++p) hybrid = hybrid && mx[p] <= n / 16;
     }
   }
@@ -845,6 +868,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     for (int p = 0; p < 2; ++p)
       for (int d = 0; d < 256; ++d) mx[p] = std::max(mx[p], h_hist_keep[p * 256 + d]);
     const double bound = static_cast<double>(mx[1]) * static_cast<double>(mx[0]) / static_cast<double>(n);
+    group_bound = bound;
     if (narrow_bits) {
       hybrid = n_live == 2 && bound <= 0.95 * kWideGroupCap;
     } else {
@@ -941,7 +965,9 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     // (two sweeps: the grouped keys are back in `keys`, the second sweep's input is intact in alt_keys)
     auto* start = static_cast<unsigned*>(c->groups.p);
     unsigned* big_list = start + kGroupCount + 1;
-    RS_HIP(c, hipMemsetAsync(big_list, 0, sizeof(unsigned), s));
+    unsigned* mid_list = big_list + kGroupCount + 1;
+    RS_HIP(c, hipMemsetAsync(big_list, 0, 2 * sizeof(unsigned), s));
+    RS_HIP(c, hipMemsetAsync(mid_list, 0, sizeof(unsigned), s));
     rsk::TableArgs t{};
     t.desc = static_cast<const uint32_t*>(desc);
     t.keys_in = last_sweep.keys_in;
@@ -954,7 +980,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     t.shift_hi = sort_begin + top_hi * rsk::kRadixBits;
     t.start = start;
     rsk::GroupArgs ga{};
-    ga.keys = keys; ga.start = start; ga.groups = kGroupCount; ga.low_bits = sort_begin + top_lo * rsk::kRadixBits;
+    ga.keys = keys; ga.start = start; ga.groups = narrow_bits ? 256u << narrow_bits : kGroupCount; ga.low_bits = sort_begin + top_lo * rsk::kRadixBits;
     ga.fmask_out = fmask; ga.smask_out = smask; ga.top_or = shared_prefix;
     ga.big_list = big_list; ga.big_cap = kGroupCount;
     ga.n = static_cast<unsigned>(n); ga.error_flag = error_flag;
@@ -962,10 +988,57 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     ba.keys = keys; ba.alt = alt_keys; ba.start = start; ba.big_list = big_list; ba.big_cap = kGroupCount; ba.low_bits = ga.low_bits;
     ba.fmask_out = fmask; ba.smask_out = smask;
     ba.n = static_cast<unsigned>(n); ba.error_flag = error_flag;
+    // As shipped (no form forced, no test window): the groups' real sizes are looked at before anything is sorted in LDS.  The
+    // bound that let the sort come this way assumes independent digits; keys of a few thousand distinct values (beyond the
+    // few-distinct path) put whole values' worth of keys into single groups, and the big-group kernel, meant for the odd
+    // oversize group, would then do most of the sort (5 * 10^7 8-byte keys of 2000 values: 7.3 ms against 1.8 for the plain
+    // loop).  More than 1/64 of the keys in groups beyond the window: the plain loop takes over from what the sweeps left, as
+    // in the pair form.  One 8-byte read-back -- which holds up the launches behind it, 40-60 us in all: sorts of at least
+    // kGroupCheckMinKeys keys only.  Smaller sorts rely on what the group kernels do by themselves: a group beyond the window
+    // whose keys are all one key is left as it is (rsk::group_oversize), and the small workgroups pass what they cannot hold
+    // on to the large ones (mid_list).
+    int fit_rc = RS_OK;
+    unsigned largest_group = 0;          // as measured (0: not measured -- a form forced, a test window)
+    auto groups_fit = [&](unsigned groups, size_t window) -> bool {
+      if (c->hybrid_mode != -1 || c->group_max_vec || n < group_check_min_keys()) return true;
+      unsigned seen[2] = {0, 0};
+      hipLaunchKernelGGL(rsk::group_max_kernel, dim3((groups + rsk::kRadix - 1) / rsk::kRadix), dim3(rsk::kRadix), 0, s, static_cast<const unsigned*>(start), big_list, groups,
+                         static_cast<unsigned>(std::min<size_t>(window, 0xFFFFFFFFu)));
+      if (hipMemcpyAsync(seen, big_list, sizeof(seen), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+          hipMemsetAsync(big_list, 0, 2 * sizeof(unsigned), s) != hipSuccess) {
+        fit_rc = fail(c, RS_ERR_KERNEL, "reading the largest group of a hybrid sort");
+        return false;
+      }
+      largest_group = seen[0];
+      if (seen[1] <= n / 64) return true;
+      c->last_hybrid = 0;
+      const int keep = c->hybrid_mode;
+      const bool keep_pre = c->precheck, keep_distinct = c->distinct_path;
+      c->hybrid_mode = 0; c->precheck = false; c->distinct_path = false;
+      fit_rc = sort_device(c, keys, vals, alt_keys, alt_vals, n, key_bytes, value_bytes, transform, begin_bit, end_bit, ws, true);
+      c->hybrid_mode = keep; c->precheck = keep_pre; c->distinct_path = keep_distinct;
+      return false;
+    };
     if (key_bytes == 4 && narrow_bits && !pair_form) {    // whole keys in LDS (the low part is wider than the 16-bit staging of the kernel below)
       hipLaunchKernelGGL(rsk::group_table_kernel<uint32_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
-      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWideGroupCap) : static_cast<unsigned>(kWideGroupCap);   // (keys, for this kernel)
-      hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(256u << narrow_bits), dim3(kWideGroupBlock), 0, s, ga);
+      const double gb = group_bound > 0 ? group_bound : 1.1 * static_cast<double>(n) / static_cast<double>(256u << narrow_bits);
+      if (!groups_fit(256u << narrow_bits, kWideGroupCap)) return fit_rc;
+      const int wg = !wide_small_blocks() ? 1024 : largest_group ? (largest_group <= 4352 ? 256 : largest_group <= 8704 ? 512 : 1024) : gb <= 0.9 * 4352 ? 256 : gb <= 0.95 * 8704 ? 512 : 1024;
+      const size_t wcap = size_t(wg) * kWideGroupItems;
+      ga.max_vec = c->group_max_vec ? static_cast<unsigned>(std::min<size_t>(size_t(c->group_max_vec) * 4u, wcap)) : static_cast<unsigned>(wcap);   // (keys, for this kernel)
+      if (wg < 1024) ga.mid_list = mid_list;
+      if (wg == 256)
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, rsk::NoVal, 256, kWideGroupItems>), dim3(256u << narrow_bits), dim3(256), 0, s, ga);
+      else if (wg == 512)
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, rsk::NoVal, 512, kWideGroupItems>), dim3(256u << narrow_bits), dim3(512), 0, s, ga);
+      else
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(256u << narrow_bits), dim3(kWideGroupBlock), 0, s, ga);
+      if (wg < 1024) {     // what the small workgroups could not hold
+        rsk::GroupArgs gm = ga;
+        gm.mid_list = nullptr; gm.from_list = mid_list;
+        gm.max_vec = c->group_max_vec ? static_cast<unsigned>(std::min<size_t>(size_t(c->group_max_vec) * 4u, kWideGroupCap)) : static_cast<unsigned>(kWideGroupCap);
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems, -1, true>), dim3(static_cast<unsigned>(c->cus)), dim3(kWideGroupBlock), 0, s, gm);
+      }
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     } else if (key_bytes == 4 && !pair_form) {
@@ -976,10 +1049,17 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       const bool small_groups = n / kGroupCount < small_group_mean_max();
       const unsigned window_vec = small_groups ? kSmallGroupBlock * kGroupMaxVec : kGroupBlock * kGroupMaxVec;
       ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, window_vec) : window_vec;
-      if (small_groups)
+      if (!groups_fit(kGroupCount, kGroupCap)) return fit_rc;
+      if (small_groups) {
+        ga.mid_list = mid_list;
         hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kSmallGroupBlock, kGroupMaxVec, 6>), dim3(kGroupCount), dim3(kSmallGroupBlock), 0, s, ga);
-      else
+        rsk::GroupArgs gm = ga;          // what the small workgroups could not hold
+        gm.mid_list = nullptr; gm.from_list = mid_list;
+        gm.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec, kGroupBlock * kGroupMaxVec) : kGroupBlock * kGroupMaxVec;
+        hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3, true>), dim3(static_cast<unsigned>(c->cus) * 3u), dim3(kGroupBlock), 0, s, gm);
+      } else {
         hipLaunchKernelGGL((rsk::group_sort_kernel<uint32_t, kGroupBlock, kGroupMaxVec, 3>), dim3(kGroupCount), dim3(kGroupBlock), 0, s, ga);
+      }
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint32_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     } else if (pair_form) {
@@ -988,7 +1068,8 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
       ga.vals = vals;
       ga.max_vec = c->group_max_vec ? static_cast<unsigned>(std::min<size_t>(size_t(c->group_max_vec) * 4u, pair_cap)) : static_cast<unsigned>(pair_cap);
       // the largest group, before anything is sorted: big_list[0] doubles as the word the maximum is gathered in
-      hipLaunchKernelGGL(rsk::group_max_kernel, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, static_cast<const unsigned*>(start), big_list);
+      RS_HIP(c, hipMemsetAsync(big_list, 0, 2 * sizeof(unsigned), s));
+      hipLaunchKernelGGL(rsk::group_max_kernel, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, static_cast<const unsigned*>(start), big_list, kGroupCount, ga.max_vec);
       unsigned largest = 0;
       RS_HIP(c, hipMemcpyAsync(&largest, big_list, sizeof(largest), hipMemcpyDeviceToHost, s));
       RS_HIP(c, hipStreamSynchronize(s));
@@ -1001,21 +1082,42 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
         c->hybrid_mode = keep;
         return rc;
       }
-      RS_HIP(c, hipMemsetAsync(big_list, 0, sizeof(unsigned), s));
+      RS_HIP(c, hipMemsetAsync(big_list, 0, 2 * sizeof(unsigned), s));
       if (key_bytes == 4 && largest <= kPair32SmallCap)
         hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, uint32_t, kPair32SmallBlock, kPair32Items>), dim3(kGroupCount), dim3(kPair32SmallBlock), 0, s, ga);
       else if (key_bytes == 4)
         hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint32_t, uint32_t, kPair32Block, kPair32Items>), dim3(kGroupCount), dim3(kPair32Block), 0, s, ga);
+      else if (largest <= 256u * kWidePairGroupItems && wide_small_blocks())
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, uint32_t, 256, kWidePairGroupItems>), dim3(kGroupCount), dim3(256), 0, s, ga);
+      else if (largest <= 512u * kWidePairGroupItems && wide_small_blocks())
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, uint32_t, 512, kWidePairGroupItems>), dim3(kGroupCount), dim3(512), 0, s, ga);
       else
         hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, uint32_t, kWideGroupBlock, kWidePairGroupItems>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
     } else {
       hipLaunchKernelGGL(rsk::group_table_kernel<uint64_t>, dim3(rsk::kRadix), dim3(rsk::kRadix), 0, s, t);
-      ga.max_vec = c->group_max_vec ? std::min<unsigned>(c->group_max_vec * 4u, kWideGroupCap) : static_cast<unsigned>(kWideGroupCap);   // (keys, for this kernel)
-      if (prefix_bits)     // (41 to 47 low bits: passes from bit 24 up, so that the prefix the fix-up works below stays 17 bits or more)
+      // groups well below the window of 1024 threads go to workgroups of 512 or 256 threads (8704 / 4352 keys), two or four to a CU
+      const double gb = group_bound > 0 ? group_bound : 1.1 * static_cast<double>(n) / static_cast<double>(narrow_bits ? 256u << narrow_bits : kGroupCount);
+      const dim3 ggrid(narrow_bits ? 256u << narrow_bits : kGroupCount);
+      if (!groups_fit(ggrid.x, kWideGroupCap)) return fit_rc;
+      const int wg = prefix_bits || !wide_small_blocks() ? 1024 : largest_group ? (largest_group <= 4352 ? 256 : largest_group <= 8704 ? 512 : 1024) : gb <= 0.9 * 4352 ? 256 : gb <= 0.95 * 8704 ? 512 : 1024;
+      const size_t wcap = size_t(wg) * kWideGroupItems;
+      ga.max_vec = c->group_max_vec ? static_cast<unsigned>(std::min<size_t>(size_t(c->group_max_vec) * 4u, wcap)) : static_cast<unsigned>(wcap);   // (keys, for this kernel)
+      if (wg < 1024) ga.mid_list = mid_list;
+      if (wg == 256)
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, 256, kWideGroupItems>), ggrid, dim3(256), 0, s, ga);
+      else if (wg == 512)
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, 512, kWideGroupItems>), ggrid, dim3(512), 0, s, ga);
+      else if (prefix_bits)     // (41 to 47 low bits: passes from bit 24 up, so that the prefix the fix-up works below stays 17 bits or more)
         hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems, 24>), dim3(kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
       else
-        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), dim3(narrow_bits ? 256u << narrow_bits : kGroupCount), dim3(kWideGroupBlock), 0, s, ga);
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems>), ggrid, dim3(kWideGroupBlock), 0, s, ga);
+      if (wg < 1024) {     // what the small workgroups could not hold
+        rsk::GroupArgs gm = ga;
+        gm.mid_list = nullptr; gm.from_list = mid_list;
+        gm.max_vec = c->group_max_vec ? static_cast<unsigned>(std::min<size_t>(size_t(c->group_max_vec) * 4u, kWideGroupCap)) : static_cast<unsigned>(kWideGroupCap);
+        hipLaunchKernelGGL((rsk::group_sort_wide_kernel<uint64_t, rsk::NoVal, kWideGroupBlock, kWideGroupItems, -1, true>), dim3(static_cast<unsigned>(c->cus)), dim3(kWideGroupBlock), 0, s, gm);
+      }
       if (c->profiling) RS_HIP(c, hipEventRecord(c->ev[ev++], s));
       hipLaunchKernelGGL((rsk::group_big_kernel<uint64_t, 512, 8>), dim3(static_cast<unsigned>(c->cus) * 2u), dim3(512), 0, s, ba);
     }

@@ -36,6 +36,9 @@ struct GroupArgs {
   uint64_t top_or;             // key bits above the group's number that every key shares (prefixed form; 16-bit staging kernel: put back with it), else 0
   unsigned* big_list;          // groups too large for the LDS window: [0] = how many, [1..] = group numbers
   unsigned big_cap;            // room in big_list (entries)
+  unsigned* mid_list;          // not null: groups beyond THIS launch's window are listed here instead (same layout, room for every group) and
+                               // a second launch, of the workgroups with the largest window, takes them from there (from_list)
+  const unsigned* from_list;   // not null: the groups to sort are the listed ones, each workgroup every gridDim.x-th of them
   unsigned max_vec;            // groups whose window has more 16-byte vectors than this are left to the big-group kernel (<= BLOCK * MAXV)
   unsigned n;                  // keys in the array: a group that does not lie inside it is reported (error word bit 3) and left alone
   unsigned* error_flag;
@@ -48,6 +51,36 @@ __device__ __forceinline__ bool group_range_ok(unsigned start, unsigned end, uns
   if (start <= end && end <= n) return true;
   if (threadIdx.x == 0) __hip_atomic_fetch_or(error_flag, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return false;
+}
+
+// A group beyond the launch's window.  With a mid_list: listed there.  Else, keys only: a group whose keys are all the same
+// key needs no sort (keys of a few thousand distinct values put whole values into single groups: without this the big-group
+// kernel, meant for the odd oversize group, did most of such a sort) -- one read of the group, and one write when the keys
+// are stored transformed; anything else goes on the big list.  Workgroup-uniform; every thread of the workgroup calls it.
+template <typename K, bool KEYS_ONLY>
+__device__ __forceinline__ void group_oversize(const GroupArgs& a, unsigned g, unsigned start, unsigned len) {
+  if (a.mid_list != nullptr) {
+    if (threadIdx.x == 0) a.mid_list[1u + atomicAdd(&a.mid_list[0], 1u)] = g;       // (room for every group)
+    return;
+  }
+  if constexpr (KEYS_ONLY) {
+    K* keys = static_cast<K*>(a.keys) + start;
+    const K first = keys[0];
+    bool differs = false;
+    for (unsigned i = threadIdx.x; i < len; i += blockDim.x) differs |= keys[i] != first;
+    if (!__syncthreads_or(differs)) {
+      const K fmo = static_cast<K>(a.fmask_out), smo = static_cast<K>(a.smask_out);
+      if (fmo | smo) {
+        const K out = xf_inverse(first, fmo, smo);
+        for (unsigned i = threadIdx.x; i < len; i += blockDim.x) keys[i] = out;
+      }
+      return;
+    }
+  }
+  if (threadIdx.x == 0) {
+    const unsigned slot = atomicAdd(&a.big_list[0], 1u);
+    if (KEYS_ONLY && slot < a.big_cap) a.big_list[1 + slot] = g;
+  }
 }
 
 template <int BLOCK, int MAXV>
@@ -297,10 +330,8 @@ __device__ __forceinline__ void group_sort_body(GroupSmem<BLOCK, MAXV>& s, K* wi
   }
 }
 
-template <typename K, int BLOCK, int MAXV, int MIN_BLOCKS>
-__global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group_sort_kernel(GroupArgs a) {
-  __shared__ GroupSmem<BLOCK, MAXV> s;
-  const unsigned g = blockIdx.x;
+template <typename K, int BLOCK, int MAXV>
+__device__ __forceinline__ void group_sort_one(GroupSmem<BLOCK, MAXV>& s, const GroupArgs& a, unsigned g) {
   const unsigned start = a.start[g], end = a.start[g + 1];
   if (!group_range_ok(start, end, a.n, a.error_flag)) return;
   if (end <= start + 1u) {                      // empty, or one key: in place already -- but the store applies the transform
@@ -311,11 +342,8 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
   const unsigned head = static_cast<unsigned>((reinterpret_cast<uintptr_t>(keys + start) & 15u) / sizeof(K));
   K* win = keys + start - head;
   const unsigned nvec = (head + len + 3u) / 4u;
-  if (nvec > a.max_vec) {   // workgroup-uniform: does not fit, left to group_big_kernel
-    if (threadIdx.x == 0) {
-      const unsigned slot = atomicAdd(&a.big_list[0], 1u);
-      if (slot < a.big_cap) a.big_list[1 + slot] = g;
-    }
+  if (nvec > a.max_vec) {   // workgroup-uniform: does not fit this window
+    group_oversize<K, true>(a, g, start, len);
     return;
   }
   const K top = (static_cast<K>(g) << a.low_bits) | static_cast<K>(a.top_or);
@@ -327,6 +355,23 @@ __global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group
     RS_GROUP_CASE(7) RS_GROUP_CASE(8) RS_GROUP_CASE(9) RS_GROUP_CASE(10) RS_GROUP_CASE(11) RS_GROUP_CASE(12)
 #undef RS_GROUP_CASE
     default: break;
+  }
+}
+
+// (LISTED: the groups of a.from_list, every gridDim.x-th one, instead of group blockIdx.x -- an instantiation of its own, see
+// group_sort_wide_kernel)
+template <typename K, int BLOCK, int MAXV, int MIN_BLOCKS, bool LISTED = false>
+__global__ __launch_bounds__(BLOCK, (MIN_BLOCKS * BLOCK + 255) / 256) void group_sort_kernel(GroupArgs a) {
+  __shared__ GroupSmem<BLOCK, MAXV> s;
+  if constexpr (!LISTED) {
+    group_sort_one<K, BLOCK, MAXV>(s, a, blockIdx.x);
+  } else {
+    const unsigned listed = min(a.from_list[0], a.groups);
+    for (unsigned i = blockIdx.x; i < listed; i += gridDim.x) {
+      const unsigned g = a.from_list[1u + i];
+      if (g < a.groups) group_sort_one<K, BLOCK, MAXV>(s, a, g);
+      __syncthreads();
+    }
   }
 }
 
@@ -374,22 +419,19 @@ template <typename K> constexpr int group_fix_top(int low) {
 // TOP_FROM: where the groups' passes start when it is not the default (bit 32 for 8-byte keys).  The prefixed form leaves
 // 41 to 47 low bits: from bit 32 that is a prefix of 9 to 15 bits and runs of two or three keys for the fix-up (11.1 ms at
 // N = 2^30); from bit 24, one pass more and runs of one key.
+// (four waves per SIMD whatever the workgroup's size -- one workgroup of 1024 threads, two of 512, four of 256 per CU: left to
+// itself the compiler takes 141-144 registers for the smaller ones and only one or three of them fit)
 template <typename K, typename V, int BLOCK, int ITEMS, int TOP_FROM = -1>
-__global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
-  __shared__ TileSortSmem<K, V, BLOCK, ITEMS> s;
+__device__ __forceinline__ void group_sort_wide_one(TileSortSmem<K, V, BLOCK, ITEMS>& s, const GroupArgs& a, unsigned g) {
   constexpr bool HAS_VAL = !__is_same(V, NoVal);
-  const unsigned g = blockIdx.x;
   const unsigned start = a.start[g], end = a.start[g + 1];
   if (!group_range_ok(start, end, a.n, a.error_flag)) return;
   if (end <= start + 1u) {
     if (end == start || !(a.fmask_out | a.smask_out)) return;
   }
   const unsigned len = end - start;
-  if (len > a.max_vec) {          // (here max_vec counts keys) workgroup-uniform: left to group_big_kernel
-    if (threadIdx.x == 0) {
-      const unsigned slot = atomicAdd(&a.big_list[0], 1u);
-      if (!HAS_VAL && slot < a.big_cap) a.big_list[1 + slot] = g;
-    }
+  if (len > a.max_vec) {          // (here max_vec counts keys) workgroup-uniform: does not fit this window
+    group_oversize<K, !HAS_VAL>(a, g, start, len);
     return;
   }
   V* gv = nullptr;
@@ -399,15 +441,45 @@ __global__ __launch_bounds__(BLOCK) void group_sort_wide_kernel(GroupArgs a) {
   group_tile_sort<K, V, BLOCK, ITEMS, (TOP_FROM >= 0 ? TOP_FROM : group_fix_top<K>((static_cast<int>(sizeof(K)) - 2) * 8))>(s, static_cast<const K*>(a.keys) + start, static_cast<K*>(a.keys) + start, gv, len,
                                                                                                static_cast<K>(a.fmask_out), static_cast<K>(a.smask_out), a.low_bits);
 }
+// LISTED: the groups of a.from_list, every gridDim.x-th one, instead of group blockIdx.x.  An instantiation of its own: with
+// the loop around it the body spills (256 bytes of scratch per lane against 16, and the 2^30-key sort loses 7 % of its group
+// kernel); the listed groups are the few that the small workgroups could not hold.
+template <typename K, typename V, int BLOCK, int ITEMS, int TOP_FROM = -1, bool LISTED = false>
+__global__ __launch_bounds__(BLOCK, 4) void group_sort_wide_kernel(GroupArgs a) {
+  __shared__ TileSortSmem<K, V, BLOCK, ITEMS> s;
+  if constexpr (!LISTED) {
+    group_sort_wide_one<K, V, BLOCK, ITEMS, TOP_FROM>(s, a, blockIdx.x);
+  } else {
+    const unsigned listed = min(a.from_list[0], a.groups);
+    for (unsigned i = blockIdx.x; i < listed; i += gridDim.x) {
+      const unsigned g = a.from_list[1u + i];
+      if (g < a.groups) group_sort_wide_one<K, V, BLOCK, ITEMS, TOP_FROM>(s, a, g);
+      __syncthreads();
+    }
+  }
+}
 
-// The largest group of a start table (pair form: asked before anything is sorted).  *out must be zero.
-__global__ __launch_bounds__(kRadix) void group_max_kernel(const unsigned* start, unsigned* out) {
+// The largest group of a start table, and how many keys lie in groups beyond `window`, asked before anything is sorted:
+// out[0] = max, out[1] = keys in oversize groups (both must be zero).  The host's bound on the largest group comes from digit
+// counts and assumes independent digits; keys of a few thousand distinct values break it.
+__global__ __launch_bounds__(kRadix) void group_max_kernel(const unsigned* start, unsigned* out, unsigned groups, unsigned window) {
   const unsigned g = blockIdx.x * kRadix + threadIdx.x;
-  const unsigned lo = start[g], hi = start[g + 1];
-  unsigned len = hi >= lo ? hi - lo : 0xFFFFFFFFu;       // (an inconsistent table: larger than any window)
+  unsigned len = 0;
+  if (g < groups) {
+    const unsigned lo = start[g], hi = start[g + 1];
+    len = hi >= lo ? hi - lo : 0xFFFFFFFFu;              // (an inconsistent table: larger than any window)
+  }
+  unsigned over = len > window ? len : 0u;
 #pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) len = max(len, static_cast<unsigned>(__shfl_down(len, off, kWave)));
-  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, len);
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    len = max(len, static_cast<unsigned>(__shfl_down(len, off, kWave)));
+    const unsigned o = static_cast<unsigned>(__shfl_down(over, off, kWave));
+    over = over + o < over ? 0xFFFFFFFFu : over + o;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    atomicMax(&out[0], len);
+    if (over) atomicAdd(&out[1], over);                  // (the sum of all groups is n < 2^32; an inconsistent table saturates one wave's share, which is then over any threshold)
+  }
 }
 
 // Mid-size sorts (at most 256 tiles; SweepArgs::mid_counts has the protocol): after ONE sweep on the top digit, workgroup g

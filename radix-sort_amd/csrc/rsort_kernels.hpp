@@ -1557,14 +1557,15 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
     if constexpr (kSplitWords) return static_cast<unsigned>(x);
     else return x;
   };
+  unsigned seen_larger = 0;                                // this thread has met a larger key of a key's run before that key (an inversion inside a run)
   auto look_left = [&](int i, unsigned r, K o) {
     const bool same = ((alive_l >> i) & 1u) && seg + i * kWave >= r && same_prefix(o, key[i]);
-    if (same && low_part(o) > low_part(key[i])) --moved_to[i];       // a larger key before this one comes to stand behind it
+    if (same && low_part(o) > low_part(key[i])) { --moved_to[i]; seen_larger = 1u; }       // a larger key before this one comes to stand behind it
     if (!same) alive_l &= ~(1u << i);
   };
   auto look_right = [&](int i, unsigned r, K o) {
     const bool same = ((alive_r >> i) & 1u) && seg + i * kWave + r < n && same_prefix(o, key[i]);
-    if (same && low_part(o) < low_part(key[i])) ++moved_to[i];       // a smaller key behind this one comes to stand before it
+    if (same && low_part(o) < low_part(key[i])) { ++moved_to[i]; seen_larger = 1u; }       // a smaller key behind this one comes to stand before it
     if (!same) alive_r &= ~(1u << i);
   };
   // One round for all the keys of the thread.  Only the LEFT neighbour is read and compared: "key p has a smaller key of its
@@ -1592,6 +1593,7 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
         }
     }
     // (alive_l now says: the key r places before is of this key's run)
+    seen_larger |= larger_before;
     const bool wrapped = lane + r >= kWave;                // the partner r places on sits in the thread set's next row
     unsigned run_on = __shfl(alive_l, static_cast<int>((lane + r) & (kWave - 1)), kWave);
     unsigned smaller_behind = __shfl(larger_before, static_cast<int>((lane + r) & (kWave - 1)), kWave);
@@ -1610,9 +1612,12 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
   };
   bool too_long = false;
   round_all(1u);
+  const bool inverted = seen_larger != 0;                  // a key of this thread stands behind a larger left neighbour of its run
   if (__any((alive_l | alive_r) != 0)) round_all(2u);
   for (unsigned r = 3; __any((alive_l | alive_r) != 0); ++r) {
-    if (r > kFixRunMax) { too_long = true; break; }
+    // (a wave whose runs go on although none of its keys has met an inversion yet: runs of one key repeated, most likely --
+    // keys of few distinct values; it stops looking, and the workgroup finds out below whether that was all)
+    if (r > kFixRunMax || (r > 3 && !__any(seen_larger != 0))) { too_long = true; break; }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const unsigned idx = seg + i * kWave;
@@ -1620,7 +1625,12 @@ __device__ __forceinline__ void tile_sort_body(Smem& s, const K* gin, K* gk, V* 
       if (__any((alive_r >> i) & 1u)) look_right(i, r, s.stage_k[((alive_r >> i) & 1u) && idx + r < n ? idx + r : 0u]);
     }
   }
-  const bool again = __syncthreads_or(too_long);           // (workgroup-uniform; also the last LDS access of the call)
+  bool again = __syncthreads_or(too_long);                 // (workgroup-uniform; also the last LDS access of the call)
+  // No key of the group stands behind a larger left neighbour of its run (round 1 compared them all): every run is in order
+  // already -- one key repeated, when the keys take a few thousand to a few million distinct values, far fewer than there
+  // are prefixes -- and nothing has moved or has to, however long the runs are.  (Without this, runs of 17 and more equal
+  // keys sent every group through all the passes again.)
+  if (again && !__syncthreads_or(inverted)) again = false;
   if (again) {                                             // the passes again, over all the bits
 #ifdef RS_FIX_STATS
     if (tid == 0) atomicAdd(RS_FIX_STATS, 1u);

@@ -129,8 +129,8 @@ def test_narrow_hybrid_matches_oracle(engine, oracle, name):
                 assert got.tobytes() == oracle.sort_keys(v, xf, mt=True).tobytes(), (name, shape, n)
                 if shape == "randomized":
                     assert form == 2, (name, n, form)
-                if shape == "duplicates":
-                    assert form == 0, (name, n, form)
+                # (duplicates, 256 values: groups of n / 256 keys -- the plain loop when the digit counts show it, else the
+                # big-group kernel behind the narrow form: either way the same result)
     finally:
         engine.lib.rs_debug_set_distinct(engine.h, 1)
         engine.set_hybrid(-1)
@@ -276,8 +276,9 @@ def test_hybrid_pair_form_prefix_runs_and_windows(engine):
             keys, perm, hybrid = _sort_pairs_on_device(engine, v, 0)
             order = np.argsort(v, kind="stable").astype(np.uint64)
             assert hybrid and keys.tobytes() == v[order].tobytes() and np.array_equal(perm, order), (prefixes, lows)
-        # 366 groups of about 12288 pairs: some fit the window, some do not -> the plain loop; 400 groups: all fit
-        for groups, expect in ((366, False), (420, True)):
+        # 366 groups of about 12288 pairs: some fit the window, some do not -> the plain loop; 420 groups: all fit;
+        # 900 / 1800 groups: they fit the windows of the 512- / 256-thread workgroups (6144 / 3072 pairs)
+        for groups, expect in ((366, False), (420, True), (900, True), (1800, True)):
             tops = rng.integers(0, groups, n, dtype=np.uint64)
             v = ((tops // np.uint64(16)) << np.uint64(56)) | ((tops % np.uint64(16)) << np.uint64(48)) | rng.integers(0, 1 << 48, n, dtype=np.uint64)
             keys, perm, hybrid = _sort_pairs_on_device(engine, v, 0)
@@ -291,6 +292,66 @@ def test_hybrid_pair_form_prefix_runs_and_windows(engine):
         assert not hybrid and keys.tobytes() == v[order].tobytes() and np.array_equal(perm, order)
     finally:
         engine.lib.rs_debug_set_group_limit(engine.h, 0)
+        engine.set_hybrid(-1)
+        engine.set_precheck(True)
+
+
+def test_hybrid_wide_groups_by_workgroup_size(engine):
+    """8-byte keys only: the group kernel in workgroups of 256, 512 and 1024 threads (windows of 4352 / 8704 / 17408 keys, picked
+    from the bound the digit counts give), groups around each window's edge (what does not fit goes to the big-group kernel),
+    low parts that exercise the fix-up; both hybrid forms."""
+    rng = np.random.Generator(np.random.PCG64(43))
+    engine.set_precheck(False)
+    engine.lib.rs_debug_set_distinct(engine.h, 0)
+    try:
+        n = 4_500_001
+        for mode in (1, 2):
+            engine.set_hybrid(mode)
+            for groups in (1300, 1100, 700, 530, 400, 270):
+                tops = rng.integers(0, groups, n, dtype=np.uint64)
+                if mode == 1:
+                    v = (tops * np.uint64(65536 // groups) << np.uint64(48)) | rng.integers(0, 1 << 48, n, dtype=np.uint64)
+                else:      # narrow form: 2^11 groups at this size, of which `groups` * 2048 / 1300 ... hold keys
+                    v = ((tops * np.uint64(2048 // groups + 1) & np.uint64(2047)) << np.uint64(53)) | rng.integers(0, 1 << 53, n, dtype=np.uint64)
+                for xf in (0, 1):
+                    keys, _ = _sort_on_device(engine, v, xf)
+                    want = np.sort(v) if xf == 0 else np.sort(v.view(np.int64)).view(np.uint64)
+                    assert keys.tobytes() == want.tobytes(), (mode, groups, xf)
+                    assert int(engine.lib.rs_debug_last_hybrid(engine.h)) in (mode, 0), (mode, groups)
+    finally:
+        engine.lib.rs_debug_set_distinct(engine.h, 1)
+        engine.set_hybrid(-1)
+        engine.set_precheck(True)
+
+
+@pytest.mark.parametrize("kb", [4, 8])
+def test_hybrid_keys_of_few_thousand_values(engine, kb):
+    """Keys that take a few hundred to a few thousand distinct values (beyond the few-distinct path, which is off here): whole
+    values land in single groups far beyond any window.  A group that is one key repeated is left as it is (and rewritten when
+    the keys are stored transformed), groups of two or three values go down the lists -- small workgroups, large ones, the
+    big-group kernel; every form, every transform, as shipped too."""
+    rng = np.random.Generator(np.random.PCG64(47))
+    dt = np.uint32 if kb == 4 else np.uint64
+    engine.set_precheck(False)
+    engine.lib.rs_debug_set_distinct(engine.h, 0)
+    try:
+        n = 4_600_003
+        for distinct in (300, 2500, 30000):
+            pool = rng.integers(0, 1 << (8 * kb), distinct, dtype=np.uint64).astype(dt)
+            pool[: distinct // 2] &= dt((1 << (8 * kb)) - 1 - 0xFFFF) if kb == 4 else dt(0xFFFFFFFF00000000)   # (values that share their top bits: groups of several values)
+            v = pool[rng.integers(0, distinct, n)]
+            for mode in (-1, 1, 2):
+                engine.set_hybrid(mode)
+                for xf in (0, 1, 2):
+                    got, _ = _sort_on_device(engine, v, xf, 1)
+                    bits = v.astype(np.uint64)
+                    sign = np.uint64(1 << (8 * kb - 1))
+                    allm = np.uint64((1 << (8 * kb)) - 1) if kb == 4 else np.uint64(0xFFFFFFFFFFFFFFFF)
+                    rank = bits if xf == 0 else bits ^ sign if xf == 1 else np.where(bits & sign, bits ^ allm, bits | sign)
+                    want = v[np.argsort(rank, kind="stable")]
+                    assert got.tobytes() == want.tobytes(), (kb, distinct, mode, xf)
+    finally:
+        engine.lib.rs_debug_set_distinct(engine.h, 1)
         engine.set_hybrid(-1)
         engine.set_precheck(True)
 
