@@ -83,8 +83,9 @@ int rs_ctx_set_tile_order(rs_ctx* ctx, int per_xcd);
  * digits only (count :125-153, prefix :193-208, scatter :447-470), after which the array is grouped by its top 16 bits,
  * and finishes every group's low 16 bits inside LDS, one workgroup per group: 28 bytes of HBM traffic per key instead of 36.
  * Same result, bit for bit (equal keys are identical, so no order among them exists to keep).
- * 8-byte keys take the same form (56 instead of 136 bytes per key; with a 4-byte payload, stable: 80 instead of 200), and
- * between about 2*10^6 and 10^8 keys a narrow one: sweeps on the top 9 to 15 bits, whole keys of every group finished in LDS.
+ * 8-byte keys take the same form (56 instead of 136 bytes per key; with a 4-byte payload, stable: 80 instead of 200; 4-byte
+ * keys with a 4-byte payload: 52 instead of 68), and between about 2*10^6 and 1.2*10^8 keys a narrow one: sweeps on the top 9
+ * to 15 bits, whole keys of every group finished in LDS.
  *   mode -1 (default): chosen per sort, from its size and its digit counts (groups must fit the LDS window);
  *   mode  0: never;   mode 1: groups of equal top 16 bits whenever the key shape allows it, at any size and distribution;
  *   mode  2: the narrow form whenever the key shape allows it;   mode 3: the prefixed form (keys that share their leading

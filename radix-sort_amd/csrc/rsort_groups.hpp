@@ -15,6 +15,10 @@
 //                        counters), LDS pass on bits 8-15 (stable: per-wave counters, as the sweep ranks), store (16 bytes
 //                        per lane).  Groups that do not fit the LDS window are left alone and put on a list
 //   group_big_kernel     the groups on that list, one workgroup each, by ranges of values through the alternate buffer
+//   group_sort_wide_kernel  whole keys (and a 4-byte payload) of a group in LDS: 8-byte keys, the narrow and the pair forms;
+//                        workgroups of 256 / 512 / 1024 threads by the size of the groups, a LISTED instantiation for the
+//                        groups the small workgroups passed on (GroupArgs::mid_list), group_oversize for what fits none
+//   group_max_kernel     the real size of the largest group, for the hosts' checks (pair forms; sorts of 5 * 10^8 keys and more)
 #pragma once
 #include "rsort_kernels.hpp"
 
