@@ -410,6 +410,49 @@ print("CHAIN HYBRID OK")
     assert r.returncode == 0 and "CHAIN HYBRID OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+def test_hybrid_hands_back_to_plain_loop_when_groups_do_not_fit():
+    """Sorts of 5 * 10^8 keys and more read their groups' real sizes back after the sweeps and, with more than 1/64 of the keys
+    in groups beyond the window, hand the array -- a stable rearrangement of the input, keys transformed -- to the plain loop.
+    Here at test size (the threshold is an environment switch read once per process: a child process), keys of 300 and
+    2500 distinct values, every transform, both widths, as shipped; few and many values for the path that stays hybrid."""
+    code = r'''
+import numpy as np, torch
+import radix_sort_amd as rs
+eng = rs.Engine(0)
+eng.set_precheck(False)
+eng.lib.rs_debug_set_distinct(eng.h, 0)
+rng = np.random.Generator(np.random.PCG64(53))
+n = 4_700_001
+back = stay = 0
+for kb in (4, 8):
+    dt = np.uint32 if kb == 4 else np.uint64
+    for distinct in (300, 2500, 1 << 22):
+        v = rng.integers(0, 1 << (8 * kb), distinct, dtype=np.uint64).astype(dt)[rng.integers(0, distinct, n)]
+        for mode in (-1,):
+            eng.set_hybrid(mode)
+            for xf in (0, 1, 2):
+                t = torch.from_numpy(v.view(np.uint8).copy()).cuda()
+                torch.cuda.synchronize()
+                eng.sort_keys_ptr(t.data_ptr(), n, kb, xf); eng.synchronize()
+                form = int(eng.lib.rs_debug_last_hybrid(eng.h))
+                bits = v.astype(np.uint64)
+                sign = np.uint64(1 << (8 * kb - 1))
+                allm = np.uint64((1 << (8 * kb)) - 1) if kb == 4 else np.uint64(0xFFFFFFFFFFFFFFFF)
+                rank = bits if xf == 0 else bits ^ sign if xf == 1 else np.where(bits & sign, bits ^ allm, bits | sign)
+                want = v[np.argsort(rank, kind="stable")]
+                assert t.cpu().numpy().view(dt).tobytes() == want.tobytes(), (kb, distinct, xf, form)
+                if kb == 8:                       # (4-byte keys of this size take the plain loop anyway)
+                    back += form == 0 and distinct <= 2500
+                    stay += form != 0 and distinct > 2500
+assert back >= 3 and stay >= 3, (back, stay)
+print("HAND BACK OK", back, stay)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSORT_GROUP_CHECK_MIN="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HAND BACK OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_hybrid_at_full_size():
     """2^30 keys, as shipped (hybrid chosen by the library): order, key sum; randomized, a ramp with swaps (nearly sorted) and
     the 256-value duplicates shape (which must NOT take the hybrid form: its groups are 4 M keys each)."""
