@@ -31,7 +31,7 @@ while time.time() < t_end:
     n = int(rng.integers(4_300_000, 8_000_000 if limit else 40_000_000))
     dt = torch.int32 if kb == 4 else torch.int64
     bits = kb * 8
-    kind = int(rng.integers(8))
+    kind = int(rng.integers(10))
     keys = rand_bits(n, kb)
     if kind == 1:                                            # few distinct keys (around the table's limit of 1024, too)
         pool = rand_bits(int(rng.choice([1, 2, 7, 256, 1000, 1024, 1025, 1500, 5000])), kb)
@@ -57,6 +57,11 @@ while time.time() < t_end:
         keys = ((keys.to(torch.int64) & ((1 << (bits - t)) - 1)) | (int(rng.integers(0, 1 << t)) << (bits - t))).to(dt)
         if rng.integers(5) == 0:
             keys[int(rng.integers(0, n))] = 3                 # ... but for one key
+    elif kind >= 8:                                          # a few thousand to a few hundred thousand distinct values: whole values in single groups
+        pool = rand_bits(int(rng.choice([1100, 3000, 20000, 300000])), kb)
+        if kind == 9:                                         # ... half of which share their top bits (groups of several values)
+            pool[: pool.numel() // 2] &= ~((1 << 20) - 1) if kb == 4 else ~((1 << 40) - 1)
+        keys = pool[torch.randint(0, pool.numel(), (n,), device="cuda")]
     hybrid = int(rng.choice([-1, -1, 1, 1, 2, 3, 3]))         # as shipped / 16-bit groups / narrow form / prefixed form forced where the shape allows
     eng.set_hybrid(hybrid)
     eng.lib.rs_debug_set_group_limit(eng.h, limit)
