@@ -122,6 +122,7 @@ constexpr size_t kHybridMinPairs = 90000000;
 // others' passes): 256 threads x 17 = 4352 keys, four per CU; 512 x 17 = 8704, two per CU.  The narrow form aims its groups at
 // the smallest window.  (2^26 / 10^8 / 2 * 10^8 / 2^28 / 4 * 10^8 keys: 1.34 / 2.88 / 3.98 / 5.21 / 6.91 -> 1.21 / 1.65 / 2.79 / 4.10 / 5.68 ms)
 constexpr double kNarrowGroupTarget = 3700;
+constexpr unsigned long long kClusteredRepeats = 3, kClusteredRepeatsWide = 1500;   // repeats among 4096 sampled keys from which on a keys-only sort is left to the plain loop (sort_device)
 constexpr unsigned kGroupCount = 65536;
 constexpr size_t kGroupsBytes = (size_t(kGroupCount) + 1) * 3 * sizeof(unsigned);   // start table + list of oversize groups + list of the groups beyond the small workgroups' window
 constexpr size_t kGroupCheckMinKeys = 500000000;   // sorts from here on look at their groups' real sizes before the LDS finish (one read-back: 40-60 us with the launches it holds up)
@@ -414,7 +415,7 @@ int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t f
   hipStream_t s = c->stream;
   constexpr size_t G = rsd::kGlobalSlots, D = rsd::kDistinctMax;
   constexpr size_t kOffCnt = G * 8, kOffOnes = kOffCnt + G * 8, kOffUsed = kOffOnes + 8, kOffSorted = kOffUsed + 8,
-                   kOffStarts = kOffSorted + (D + 1) * 8, kOffSpan = kOffStarts + (D + 2) * 8, kBytes = kOffSpan + 16;
+                   kOffStarts = kOffSorted + (D + 1) * 8, kOffSpan = kOffStarts + (D + 2) * 8, kBytes = kOffSpan + 24;
   int rc;
   if ((rc = ensure(c, c->distinct, kBytes)) != RS_OK) return rc;
   char* d = static_cast<char*>(c->distinct.p);
@@ -433,12 +434,14 @@ int sort_few_distinct(rs_ctx* c, void* keys, size_t n, int key_bytes, uint64_t f
   // (riding on the same wait: which key bits differ at all, over a sample spread across the array -- sort_device's narrow form asks)
   auto* d_span = reinterpret_cast<unsigned long long*>(d + kOffSpan);
   RS_HIP(c, hipMemsetAsync(d_span, 0xFF, 8, s));
-  RS_HIP(c, hipMemsetAsync(d_span + 1, 0, 8, s));
+  RS_HIP(c, hipMemsetAsync(d_span + 1, 0, 16, s));
   if (key_bytes == 4) hipLaunchKernelGGL(rsd::bit_span_kernel<uint32_t>, dim3(1), dim3(1024), 0, s, static_cast<const uint32_t*>(keys), static_cast<uint64_t>(n), d_span);
   else hipLaunchKernelGGL(rsd::bit_span_kernel<uint64_t>, dim3(1), dim3(1024), 0, s, static_cast<const uint64_t*>(keys), static_cast<uint64_t>(n), d_span);
   RS_HIP(c, hipMemcpyAsync(used, a.used, 8, hipMemcpyDeviceToHost, s));
-  RS_HIP(c, hipMemcpyAsync(span, d_span, 16, hipMemcpyDeviceToHost, s));
+  unsigned long long got[3] = {0, 0, 0};
+  RS_HIP(c, hipMemcpyAsync(got, d_span, 24, hipMemcpyDeviceToHost, s));
   RS_HIP(c, hipStreamSynchronize(s));
+  span[0] = got[0]; span[1] = got[1]; span[3] = got[2];
   span[2] = 1;                                              // known
   if (used[0] > D) return RS_OK;
   // 2. the whole array
@@ -585,7 +588,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // descriptor buffer, and -- below -- no host synchronisation at all.
   const bool mid = tiles <= kAlwaysSweepTiles && !wide;
   int rc;
-  unsigned long long span[3] = {0, 0, 0};     // AND and OR of a sample of the keys, [2] = known (sort_few_distinct)
+  unsigned long long span[4] = {0, 0, 0, 0};     // AND and OR of a sample of the keys, [2] = known, [3] = repeats among the 4096 sampled keys (sort_few_distinct)
   if (!ws) {
     if ((rc = ensure(c, c->ctrl, kCtrlBytesChain)) != RS_OK) return rc;
     if (!mid && (rc = ensure(c, c->desc, desc_bytes_for(n))) != RS_OK) return rc;
@@ -678,6 +681,13 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // each (the window of the smallest workgroups of the group kernel, four of which share a CU) -- the sort is then a sort on the bit range [sort_begin, end_bit) (two digits: 8 bits and, on top, b bits) followed
   // by the wide group kernel on the bits below.  Decided from n alone, before the histogram (which then covers only the two
   // swept digits); whether the groups really fit is known from those counts, and the plain loop takes over when they do not.
+  // Keys of a few thousand to a few million distinct values (the sample's repeats say so, when the few-distinct probe ran):
+  // every value's copies share one group, whose low digits then take one or two values -- the group sorts' LDS counters
+  // queue, groups outgrow their windows -- and the plain loop is the faster form (4-byte keys: 3 * 10^8 keys of 2 * 10^4 /
+  // 2 * 10^5 values 7.3 / 3.9 ms against 2.9; at 2 * 10^6 values, 4 repeats expected, even).  8-byte keys cope with all but
+  // the smallest pools, so their limit is a few thousand values.  As shipped only: a forced form stays forced.
+  const unsigned long long sample_repeats = span[2] ? span[3] : 0;
+  const bool clustered = c->hybrid_mode == -1 && sample_repeats >= (key_bytes == 4 ? kClusteredRepeats : kClusteredRepeatsWide);
   int sort_begin = begin_bit, narrow_bits = 0;
   if ((c->hybrid_mode == -1 || c->hybrid_mode == 2) && !ws && !mid && !wide && !forward_done && value_bytes == 0 && (key_bytes == 4 || key_bytes == 8) &&
       begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic && (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0 &&
@@ -688,7 +698,9 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     // all differ somewhere, or the groups cannot be balanced -- 8-byte keys that hold small integers -- and the plain loop,
     // which skips constant digits, is the better start.  A hint only: the histogram below still decides.)
     const unsigned long long need = ((1ull << g) - 1ull) << (end_bit - g);
-    if (!span[2] || (((span[0] ^ span[1]) & need) == need) || c->hybrid_mode == 2) {
+    if (clustered) {
+      // (the plain loop)
+    } else if (!span[2] || (((span[0] ^ span[1]) & need) == need) || c->hybrid_mode == 2) {
       narrow_bits = g - 8;
       sort_begin = end_bit - g;
       passes = 2;
@@ -701,7 +713,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
   // swept, and on top a partial digit of t bits that must come out constant -- the histogram says so exactly, the sample
   // (span) only suggests it -- followed by the in-LDS finish of the end - t - 16 bits below.
   int prefix_bits = 0;
-  if (!narrow_bits && (c->hybrid_mode == -1 || c->hybrid_mode == 3) && span[2] && !ws && !mid && !forward_done && value_bytes == 0 &&
+  if (!narrow_bits && !clustered && (c->hybrid_mode == -1 || c->hybrid_mode == 3) && span[2] && !ws && !mid && !forward_done && value_bytes == 0 &&
       (key_bytes == 4 || key_bytes == 8) && begin_bit == 0 && end_bit == key_bytes * 8 && c->rank_by_lds_atomic &&
       (reinterpret_cast<uintptr_t>(keys) & static_cast<uintptr_t>(key_bytes - 1)) == 0 && n < (size_t(1) << 32) &&
       (c->hybrid_mode == 3 || n >= (key_bytes == 4 ? kHybridMinKeys : hybrid_min_keys_wide()))) {
@@ -858,7 +870,7 @@ int sort_device(rs_ctx* c, void* keys, void* vals, void* alt_keys, void* alt_val
     if (hybrid_env == 1) {
       hybrid = true;
     } else {
-      hybrid = n >= (pair_form ? (key_bytes == 4 ? kHybridMinPairs : kHybridMinPairsWide) : key_bytes == 4 ? kHybridMinKeys : hybrid_min_keys_wide()) && bound <= (key_bytes == 8 && !pair_form ? 0.97 : 0.95) * group_cap;
+      hybrid = !clustered && n >= (pair_form ? (key_bytes == 4 ? kHybridMinPairs : kHybridMinPairsWide) : key_bytes == 4 ? kHybridMinKeys : hybrid_min_keys_wide()) && bound <= (key_bytes == 8 && !pair_form ? 0.97 : 0.95) * group_cap;
       for (int p = 0; p < top_lo; ++p) hybrid = hybrid && mx[p] <= n / 16;
     }
   }
